@@ -1,0 +1,165 @@
+/* urt.h — C ABI of libunityraytracer_amd.so: the MI355X (gfx950) replacement for the GPU calls that
+ * RemyMuj/UnityRayTracer's Assets/Scripts/RayTraceMaster.cs ("RM") makes through UnityEngine:
+ * ComputeBuffer / ComputeShader.Set* / ComputeShader.Dispatch / RenderTexture / Graphics.Blit.
+ * Each entry point cites the reference call site it stands in for; the C# P/Invoke shim that binds
+ * them is shown in INTEGRATION.md.  The kernels behind urt_shader_dispatch()/urt_blit_add() are
+ * hand-written HIP restatements of Assets/Shaders/RayTraceShader.compute ("RS", kernel CSMain) and
+ * Assets/Shaders/AdditionShader.shader ("AS").
+ *
+ * Conventions:
+ *  - plain C types only; every function returns an int status (URT_OK == 0) and never unwinds;
+ *    urt_last_error() returns the message for the last non-zero status (Unity's API returns void
+ *    and logs — a caller that wants that behaviour logs the string and carries on);
+ *  - host memory passed in is copied before the call returns (ComputeBuffer.SetData semantics);
+ *  - handles are opaque 64-bit ids owned by the library until *_release();
+ *  - one caller thread per context (Unity main thread); work is issued in order on one HIP stream,
+ *    so no synchronisation is needed between dispatch and blit; urt_synchronize() or a readback
+ *    waits for completion;
+ *  - buffer layouts are the byte layouts of urt_types.h (RM:42-45), matrices are 16 floats in
+ *    Unity Matrix4x4 memory order (column-major), images are RGBA32F with row 0 = bottom row
+ *    (RS:434,468: id.y = 0 is uv.y = -1);
+ *  - there is no CPU fallback: every entry point that needs the GPU fails with
+ *    URT_ERR_NO_DEVICE if no HIP device is usable.
+ */
+#pragma once
+#include <stdint.h>
+#include "urt_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define URT_API __attribute__((visibility("default")))
+
+typedef struct urt_context urt_context;
+typedef uint64_t urt_handle;
+
+enum {
+  URT_OK = 0,
+  URT_ERR_INVALID_ARGUMENT = 1,
+  URT_ERR_INVALID_HANDLE = 2,
+  URT_ERR_NO_DEVICE = 3,
+  URT_ERR_HIP = 4,
+  URT_ERR_UNBOUND = 5,        /* dispatch without a Result texture / camera matrices */
+  URT_ERR_LAYOUT = 6,         /* stride/count does not match the layout the name requires */
+  URT_ERR_OUT_OF_MEMORY = 7,
+  URT_ERR_SCENE = 8           /* scene data fails validation (index out of range, stack too deep) */
+};
+
+/* ---- library / context ------------------------------------------------------------------- */
+URT_API int urt_abi_version(void);                       /* bumps when this header changes */
+URT_API int urt_device_count(int* out_count);
+/* One context per process and GPU (the one-process-per-GPU model).  device = HIP ordinal. */
+URT_API int urt_context_create(int device, urt_context** out_ctx);
+URT_API int urt_context_destroy(urt_context* ctx);
+/* Message for the last failing call on ctx (ctx may be NULL for create failures). Never NULL. */
+URT_API const char* urt_last_error(urt_context* ctx);
+/* Issue all work on a caller-owned hipStream_t (e.g. torch's current stream); NULL = own stream. */
+URT_API int urt_context_set_stream(urt_context* ctx, void* hip_stream);
+/* Block until everything issued so far is complete. */
+URT_API int urt_synchronize(urt_context* ctx);
+
+/* ---- ComputeBuffer ------------------------------------------------------------------------ */
+/* new ComputeBuffer(count, stride)                                   RM:247 */
+URT_API int urt_buffer_create(urt_context* ctx, int count, int stride, urt_handle* out_buffer);
+/* buffer.SetData(List<T>) — synchronous copy of count*stride bytes   RM:250 */
+URT_API int urt_buffer_set_data(urt_context* ctx, urt_handle buffer, const void* data, int count);
+/* buffer.count / buffer.stride                                       RM:237 */
+URT_API int urt_buffer_get_info(urt_context* ctx, urt_handle buffer, int* out_count, int* out_stride);
+/* buffer.Release()                                                   RM:195-210, 238 */
+URT_API int urt_buffer_release(urt_context* ctx, urt_handle buffer);
+
+/* ---- RenderTexture / Texture (RGBA32F = ARGBFloat, linear) -------------------------------- */
+/* new RenderTexture(w, h, 0, ARGBFloat, Linear){enableRandomWrite}.Create()   RM:834-840 */
+URT_API int urt_texture_create(urt_context* ctx, int width, int height, urt_handle* out_texture);
+/* Same, over caller-owned device memory of width*height*16 bytes (e.g. a torch tensor that a
+ * collective reads); the library never frees it. */
+URT_API int urt_texture_create_external(urt_context* ctx, int width, int height, void* device_ptr,
+                                        urt_handle* out_texture);
+/* Upload / read back width*height*4 floats, row 0 = bottom.  (sky texture upload; readback stands
+ * in for presenting _converged, RM:819.)  Both synchronise. */
+URT_API int urt_texture_set_pixels(urt_context* ctx, urt_handle texture, const float* rgba);
+URT_API int urt_texture_get_pixels(urt_context* ctx, urt_handle texture, float* rgba);
+URT_API int urt_texture_get_info(urt_context* ctx, urt_handle texture, int* out_width, int* out_height,
+                                 void** out_device_ptr);
+/* texture.Release()                                                  RM:830-831 */
+URT_API int urt_texture_release(urt_context* ctx, urt_handle texture);
+
+/* ---- ComputeShader (RayTraceShader.compute; kernel index 0 = CSMain) ---------------------- */
+/* shader.SetBuffer(0, name, buffer)                                  RM:255-259, names RM:787-794:
+ *   _MeshObjects(112) _Vertices(12) _Indices(4) _Normals(12) _Spheres(56) _MeshBVH(28) _SphereBVH(28)
+ * A name that was never bound counts as an empty buffer (RM:256 skips null; RS:375-379).
+ * buffer == 0 unbinds. */
+URT_API int urt_shader_set_buffer(urt_context* ctx, int kernel, const char* name, urt_handle buffer);
+/* shader.SetTexture(0, "_SkyboxTexture" | "Result", tex)             RM:776, RM:803 */
+URT_API int urt_shader_set_texture(urt_context* ctx, int kernel, const char* name, urt_handle texture);
+/* shader.SetMatrix("_CameraToWorld" | "_CameraInverseProjection", m) RM:773-774 */
+URT_API int urt_shader_set_matrix(urt_context* ctx, const char* name, const float* m16);
+/* shader.SetVector("_PixelOffset", v)  (x,y used)                    RM:777 */
+URT_API int urt_shader_set_vector(urt_context* ctx, const char* name, const float* v4);
+/* shader.SetFloat("_Seed", v)                                        RM:778 */
+URT_API int urt_shader_set_float(urt_context* ctx, const char* name, float value);
+/* shader.SetInt("_numBounces" | "_numRays", v); "_MeshBVH_len" / "_SphereBVH_len" are accepted and
+ * ignored (they are `static const` in the shader, RS:73-74).         RM:780-784
+ * Names the shader does not declare are ignored, as Unity does. */
+URT_API int urt_shader_set_int(urt_context* ctx, const char* name, int value);
+/* shader.Dispatch(0, groupsX, groupsY, 1): one thread per pixel in 8x8 groups; threads outside the
+ * Result texture write nothing.  Asynchronous, in order.            RM:806-810 -> RS:431-469 */
+URT_API int urt_shader_dispatch(urt_context* ctx, int kernel, int groups_x, int groups_y, int groups_z);
+/* Multi-GPU form: the same dispatch restricted to group rows first_group_row, +row_stride, ...
+ * (8 pixel rows each).  Pixels keep their GLOBAL id.xy, so the union over ranks
+ * r = 0..N-1 of dispatch_rows(r, N) is bit-identical to one full dispatch (RS:78,434). */
+URT_API int urt_shader_dispatch_rows(urt_context* ctx, int kernel, int groups_x, int groups_y, int groups_z,
+                                     int first_group_row, int row_stride);
+
+/* ---- Graphics.Blit ------------------------------------------------------------------------ */
+/* _additionMaterial.SetFloat("_Sample", sample); Graphics.Blit(src, dst, _additionMaterial):
+ * dst = src * a + dst * (1 - a) with a = 1 / (sample + 1), all four channels   RM:817-818, AS:9,39-41 */
+URT_API int urt_blit_add(urt_context* ctx, urt_handle src, urt_handle dst, float sample);
+/* Graphics.Blit(src, dst): copy                                      RM:819 */
+URT_API int urt_blit(urt_context* ctx, urt_handle src, urt_handle dst);
+/* Strip helpers for the frame-end gather: copy the 8-row strips first_group_row, +row_stride, ... of
+ * an image to/from a dense device buffer (strip-major).  out_bytes reports the packed size. */
+URT_API int urt_texture_pack_rows(urt_context* ctx, urt_handle texture, int first_group_row, int row_stride,
+                                  void* device_dst, uint64_t* out_bytes);
+URT_API int urt_texture_unpack_rows(urt_context* ctx, urt_handle texture, int first_group_row, int row_stride,
+                                    const void* device_src);
+
+/* ---- measurement -------------------------------------------------------------------------- */
+typedef struct urt_counters {
+  uint64_t rays;          /* Trace() invocations (RS:454) — the unit of the Mrays/s metric */
+  uint64_t tlas_nodes;    /* object-level BVHNode fetches, 28 B each (RS:306, RS:341) */
+  uint64_t blas_nodes;    /* triangle-BVH node visits, 64 B each */
+  uint64_t tri_tests;     /* Moller-Trumbore evaluations, 48 B each (RS:199-234) */
+  uint64_t sphere_tests;  /* IntersectSphere evaluations, 16 B each (RS:175-196) */
+  uint64_t hit_tri;       /* closest hits shaded on a triangle: 48 B normals + 40 B material */
+  uint64_t hit_sphere;    /* closest hits shaded on a sphere: 40 B material */
+  uint64_t hit_ground;    /* closest hits on the y = 0 plane */
+  uint64_t hit_sky;       /* paths ended on the sky: 4 x 16 B texels */
+  uint64_t pixels;        /* pixels written (16 B each) */
+  uint64_t dispatches;    /* urt_shader_dispatch* calls since reset */
+  float trace_ms;         /* GPU time of the trace kernels of those dispatches (HIP events) */
+  float reserved;
+} urt_counters;
+/* Options: "count_stats" (0/1: per-dispatch traversal counters, slower build of the kernel),
+ *          "time_dispatch" (0/1: bracket each dispatch with HIP events, read by urt_get_counters),
+ *          "kernel_mode" (0 = per-pixel megakernel, 1 = wavefront with ray compaction; default 1). */
+URT_API int urt_set_option(urt_context* ctx, const char* name, int value);
+URT_API int urt_get_counters(urt_context* ctx, urt_counters* out);   /* synchronises */
+URT_API int urt_reset_counters(urt_context* ctx);
+
+/* ---- introspection for tests (host only, no GPU needed) ------------------------------------ */
+/* Run the library's triangle-BVH builder — the one urt_shader_dispatch uses — over host copies of
+ * _MeshObjects (112 B records), _Vertices, _Indices, and keep the result in a process-wide cache.
+ * Reports the sizes.  tests/ use it to validate the BVH and to hand it to the oracle's culled mode. */
+URT_API int urt_debug_build_blas(const void* mesh_objects, int n_meshes, const float* vertices, int n_vertices,
+                                 const int32_t* indices, int n_indices, int* out_n_nodes, int* out_n_tris,
+                                 int* out_max_depth);
+/* Copy the cached BVH out: nodes = n_nodes * 16 floats (layout in DESIGN.md "BLAS"); tri_index = n_tris
+ * index-slot numbers (i of RS:243) in leaf order; mesh_root / mesh_first_tri = one entry per MeshObject.
+ * Any pointer may be NULL. */
+URT_API int urt_debug_get_blas(float* nodes, int32_t* tri_index, int32_t* mesh_root, int32_t* mesh_first_tri);
+
+#ifdef __cplusplus
+}
+#endif

@@ -1,0 +1,98 @@
+"""ctypes binding of libunityraytracer_amd.so (include/urt.h).
+
+The shared library is the product: hand-written HIP kernels + the C ABI.  It is built in-tree by
+`unityraytracer_amd.build.build_library()` (hipcc, gfx950).  There is no fallback of any kind: if the
+library is missing this module raises, and if no GPU is usable `Context()` raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libunityraytracer_amd.so")
+
+URT_OK = 0
+ERROR_NAMES = {1: "INVALID_ARGUMENT", 2: "INVALID_HANDLE", 3: "NO_DEVICE", 4: "HIP", 5: "UNBOUND", 6: "LAYOUT", 7: "OUT_OF_MEMORY", 8: "SCENE"}
+
+# every symbol include/urt.h declares (tests check that the .so exports each of them)
+ABI_SYMBOLS = [
+    "urt_abi_version", "urt_device_count", "urt_context_create", "urt_context_destroy", "urt_last_error", "urt_context_set_stream",
+    "urt_synchronize", "urt_buffer_create", "urt_buffer_set_data", "urt_buffer_get_info", "urt_buffer_release", "urt_texture_create",
+    "urt_texture_create_external", "urt_texture_set_pixels", "urt_texture_get_pixels", "urt_texture_get_info", "urt_texture_release",
+    "urt_shader_set_buffer", "urt_shader_set_texture", "urt_shader_set_matrix", "urt_shader_set_vector", "urt_shader_set_float",
+    "urt_shader_set_int", "urt_shader_dispatch", "urt_shader_dispatch_rows", "urt_blit_add", "urt_blit", "urt_texture_pack_rows",
+    "urt_texture_unpack_rows", "urt_set_option", "urt_get_counters", "urt_reset_counters", "urt_debug_build_blas", "urt_debug_get_blas",
+]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("rays", "tlas_nodes", "blas_nodes", "tri_tests", "sphere_tests", "hit_tri", "hit_sphere",
+                                          "hit_ground", "hit_sky", "pixels", "dispatches")] + [("trace_ms", C.c_float), ("reserved", C.c_float)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
+
+
+class UrtError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"URT_ERR_{ERROR_NAMES.get(code, code)}: {message}")
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library, declaring every prototype.  Raises ImportError when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the HIP path.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i, f, u64 = C.c_void_p, C.c_int, C.c_float, C.c_uint64
+    pi, pf = C.POINTER(C.c_int), C.POINTER(C.c_float)
+    protos = {
+        "urt_abi_version": ([], i),
+        "urt_device_count": ([pi], i),
+        "urt_context_create": ([i, C.POINTER(vp)], i),
+        "urt_context_destroy": ([vp], i),
+        "urt_last_error": ([vp], C.c_char_p),
+        "urt_context_set_stream": ([vp, vp], i),
+        "urt_synchronize": ([vp], i),
+        "urt_buffer_create": ([vp, i, i, C.POINTER(u64)], i),
+        "urt_buffer_set_data": ([vp, u64, vp, i], i),
+        "urt_buffer_get_info": ([vp, u64, pi, pi], i),
+        "urt_buffer_release": ([vp, u64], i),
+        "urt_texture_create": ([vp, i, i, C.POINTER(u64)], i),
+        "urt_texture_create_external": ([vp, i, i, vp, C.POINTER(u64)], i),
+        "urt_texture_set_pixels": ([vp, u64, vp], i),
+        "urt_texture_get_pixels": ([vp, u64, vp], i),
+        "urt_texture_get_info": ([vp, u64, pi, pi, C.POINTER(vp)], i),
+        "urt_texture_release": ([vp, u64], i),
+        "urt_shader_set_buffer": ([vp, i, C.c_char_p, u64], i),
+        "urt_shader_set_texture": ([vp, i, C.c_char_p, u64], i),
+        "urt_shader_set_matrix": ([vp, C.c_char_p, vp], i),
+        "urt_shader_set_vector": ([vp, C.c_char_p, vp], i),
+        "urt_shader_set_float": ([vp, C.c_char_p, f], i),
+        "urt_shader_set_int": ([vp, C.c_char_p, i], i),
+        "urt_shader_dispatch": ([vp, i, i, i, i], i),
+        "urt_shader_dispatch_rows": ([vp, i, i, i, i, i, i], i),
+        "urt_blit_add": ([vp, u64, u64, f], i),
+        "urt_blit": ([vp, u64, u64], i),
+        "urt_texture_pack_rows": ([vp, u64, i, i, vp, C.POINTER(u64)], i),
+        "urt_texture_unpack_rows": ([vp, u64, i, i, vp], i),
+        "urt_set_option": ([vp, C.c_char_p, i], i),
+        "urt_get_counters": ([vp, C.POINTER(Counters)], i),
+        "urt_reset_counters": ([vp], i),
+        "urt_debug_build_blas": ([vp, i, vp, i, vp, i, pi, pi, pi], i),
+        "urt_debug_get_blas": ([vp, vp, vp, vp], i),
+    }
+    assert sorted(protos) == sorted(ABI_SYMBOLS)
+    for name, (args, res) in protos.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = res
+    _lib = lib
+    return lib

@@ -1,0 +1,56 @@
+"""Build recipes (in-tree, explicit hipcc — no JIT cache): the HIP library and the test-only oracle."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+CSRC = os.path.join(_HERE, "csrc")
+LIB = os.path.join(_HERE, "libunityraytracer_amd.so")
+
+HIPCC_FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17",
+    "-ffp-contract=off",            # normative arithmetic: no implicit fma (include/urt_math.h)
+    "-fPIC", "-shared", "-fvisibility=hidden",
+    "-Xarch_host", "-march=x86-64-v3",   # inline hardware fma for the host-side vertex pre-transform
+    "-Wall", "-Wno-unused-function",
+]
+SOURCES = ["kernels.hip", "context.cpp", "blas_builder.cpp"]
+
+
+def _newer(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(d) <= t for d in deps)
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 ... -> unityraytracer_amd/libunityraytracer_amd.so (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")] + \
+        [os.path.join(_ROOT, "include", h) for h in os.listdir(os.path.join(_ROOT, "include"))]
+    if not force and _newer(LIB, deps):
+        return LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True, cwd=_HERE)
+    return LIB
+
+
+def build_oracle(force: bool = False) -> str:
+    """make -C oracle -> oracle/liboracle.so (g++, -ffp-contract=off).  Test infrastructure only."""
+    odir = os.path.join(_ROOT, "oracle")
+    if force:
+        subprocess.run(["make", "-C", odir, "clean"], check=True, stdout=subprocess.DEVNULL)
+    subprocess.run(["make", "-C", odir], check=True, stdout=subprocess.DEVNULL)
+    return os.path.join(odir, "liboracle.so")
+
+
+if __name__ == "__main__":
+    print(build_library(force=True, verbose=True))
+    print(build_oracle())

@@ -1,0 +1,209 @@
+// blas_builder.cpp — host-side triangle-BVH ("BLAS") builder.
+//
+// The reference has no triangle-level acceleration structure: IntersectMeshObject tests every triangle
+// of a mesh per ray (RayTraceShader.compute:243-266), which is why it is "very slow for complex
+// scenes" (reference README.md:2).  This builder turns the reference's own buffers (_Vertices,
+// _Indices, _MeshObjects as uploaded through urt_buffer_set_data) into one binned-SAH BVH per
+// MeshObject over WORLD-SPACE triangles: the per-ray `mul(localToWorldMatrix, float4(v,1))` of
+// RS:244-246 is applied once here with the same normative formula (urt::mul_m4), so the triangle
+// test on the GPU sees bit-identical vertices.
+//
+// Output (layouts in urt_device.h): 64-byte nodes holding both children's boxes, leaf-ordered
+// triangle records (v0, e1 = v1-v0, e2 = v2-v0, index slot, mesh id) and leaf-ordered vertex normals.
+// Child boxes are padded by 2^-16 * (largest |coordinate| of the mesh) so that the slab test can never
+// cull a triangle that the float32 Moller-Trumbore test would accept (DESIGN.md "BLAS traversal").
+#include "blas_builder.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+#include "../../include/urt_math.h"
+
+namespace urtd {
+
+namespace {
+
+struct Prim {
+  float lo[3], hi[3], c[3];
+  int32_t slot;   // index slot i of RS:243 (global position in _Indices, multiple of 3 from the mesh offset)
+};
+
+struct Box {
+  float lo[3], hi[3];
+  void reset() { for (int k = 0; k < 3; k++) { lo[k] = std::numeric_limits<float>::infinity(); hi[k] = -lo[k]; } }
+  void grow(const float* l, const float* h) { for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], l[k]); hi[k] = std::max(hi[k], h[k]); } }
+  float half_area() const {
+    float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    if (!(dx >= 0) || !(dy >= 0) || !(dz >= 0)) return 0.0f;
+    return dx * dy + dy * dz + dz * dx;
+  }
+};
+
+constexpr int kBins = 16;
+constexpr int kLeafMax = 4;      // SAH leaves
+constexpr int kLeafHardMax = 8;  // encoding limit (3 bits)
+
+struct Builder {
+  std::vector<Prim> prims;
+  BlasResult& out;
+  float pad = 0;
+  int mesh_id = 0;
+  int max_depth = 0;
+  explicit Builder(BlasResult& o) : out(o) {}
+
+  int32_t make_leaf(int lo, int hi) {
+    uint32_t first = (uint32_t)out.tri_slot.size();
+    for (int q = lo; q < hi; q++) { out.tri_slot.push_back(prims[q].slot); out.tri_mesh.push_back(mesh_id); }
+    uint32_t code = (first << 3) | (uint32_t)(hi - lo - 1);
+    return (int32_t)~code;
+  }
+
+  // returns the child code for prims[lo,hi) and writes its (padded) box
+  int32_t build(int lo, int hi, int depth, Box& box) {
+    max_depth = std::max(max_depth, depth);
+    int n = hi - lo;
+    box.reset();
+    Box cb; cb.reset();
+    for (int q = lo; q < hi; q++) { box.grow(prims[q].lo, prims[q].hi); cb.grow(prims[q].c, prims[q].c); }
+    if (n <= kLeafMax) return make_leaf(lo, hi);
+
+    // binned SAH over the three axes
+    int best_axis = -1, best_bin = -1;
+    float best_cost = std::numeric_limits<float>::infinity();
+    for (int ax = 0; ax < 3; ax++) {
+      float ext = cb.hi[ax] - cb.lo[ax];
+      if (!(ext > 0)) continue;
+      int cnt[kBins] = {0};
+      Box bb[kBins];
+      for (auto& b : bb) b.reset();
+      float scale = (float)kBins / ext;
+      for (int q = lo; q < hi; q++) {
+        int b = (int)((prims[q].c[ax] - cb.lo[ax]) * scale);
+        b = std::min(std::max(b, 0), kBins - 1);
+        cnt[b]++; bb[b].grow(prims[q].lo, prims[q].hi);
+      }
+      float right_area[kBins]; int right_cnt[kBins];
+      Box acc; acc.reset(); int c = 0;
+      for (int b = kBins - 1; b > 0; b--) { acc.grow(bb[b].lo, bb[b].hi); c += cnt[b]; right_area[b] = acc.half_area(); right_cnt[b] = c; }
+      acc.reset(); c = 0;
+      for (int b = 0; b < kBins - 1; b++) {
+        acc.grow(bb[b].lo, bb[b].hi); c += cnt[b];
+        if (c == 0 || right_cnt[b + 1] == 0) continue;
+        float cost = acc.half_area() * (float)c + right_area[b + 1] * (float)right_cnt[b + 1];
+        if (cost < best_cost) { best_cost = cost; best_axis = ax; best_bin = b; }
+      }
+    }
+    int mid;
+    if (best_axis >= 0) {
+      float ext = cb.hi[best_axis] - cb.lo[best_axis];
+      float scale = (float)kBins / ext;
+      float clo = cb.lo[best_axis];
+      int ax = best_axis, bin = best_bin;
+      auto it = std::partition(prims.begin() + lo, prims.begin() + hi, [=](const Prim& p) {
+        int b = (int)((p.c[ax] - clo) * scale);
+        b = std::min(std::max(b, 0), kBins - 1);
+        return b <= bin;
+      });
+      mid = (int)(it - prims.begin());
+    } else {
+      mid = lo;   // all centroids coincide
+    }
+    if (mid == lo || mid == hi || depth > 56) {
+      if (n <= kLeafHardMax && best_axis < 0) return make_leaf(lo, hi);
+      mid = (lo + hi) / 2;   // median by current order: keeps the tree finite for degenerate input
+    }
+    int32_t me = (int32_t)(out.nodes.size() / kBlasNodeFloats);
+    out.nodes.resize(out.nodes.size() + kBlasNodeFloats, 0.0f);
+    Box b0, b1;
+    int32_t c0 = build(lo, mid, depth + 1, b0);
+    int32_t c1 = build(mid, hi, depth + 1, b1);
+    float* nd = out.nodes.data() + (size_t)me * kBlasNodeFloats;
+    for (int k = 0; k < 3; k++) {
+      nd[k] = b0.lo[k] - pad; nd[3 + k] = b0.hi[k] + pad;
+      nd[6 + k] = b1.lo[k] - pad; nd[9 + k] = b1.hi[k] + pad;
+    }
+    nd[12] = urt::bits_f((uint32_t)c0);
+    nd[13] = urt::bits_f((uint32_t)c1);
+    return me;
+  }
+};
+
+}  // namespace
+
+bool build_blas(const uint8_t* mesh_objects, int n_meshes, const float* vertices, int n_vertices, const int32_t* indices,
+                int n_indices, const float* normals, int n_normals, BlasResult& out, std::string& err) {
+  out = BlasResult();
+  out.mesh_root.assign((size_t)n_meshes, kEmptyMeshRoot);
+  out.mesh_first_tri.assign((size_t)n_meshes, 0);
+  for (int m = 0; m < n_meshes; m++) {
+    urt_MeshObject mo;
+    std::memcpy(&mo, mesh_objects + (size_t)m * sizeof(urt_MeshObject), sizeof mo);
+    long off = mo.indices_offset, cnt = mo.indices_count;
+    if (off < 0 || cnt < 0 || off + cnt > n_indices) {
+      err = "MeshObject " + std::to_string(m) + ": indices_offset/count outside _Indices";
+      return false;
+    }
+    Builder B(out);
+    B.mesh_id = m;
+    float ext = 0;
+    B.prims.reserve((size_t)(cnt / 3));
+    for (long i = off; i + 2 < off + cnt; i += 3) {
+      Prim p; p.slot = (int32_t)i;
+      for (int k = 0; k < 3; k++) { p.lo[k] = std::numeric_limits<float>::infinity(); p.hi[k] = -p.lo[k]; }
+      for (int j = 0; j < 3; j++) {
+        int32_t vi = indices[i + j];
+        if (vi < 0 || vi >= n_vertices || (normals && vi >= n_normals)) {
+          err = "_Indices[" + std::to_string(i + j) + "] = " + std::to_string(vi) + " is outside _Vertices/_Normals";
+          return false;
+        }
+        const float* v = vertices + 3 * (size_t)vi;
+        urt::v3 w = urt::mul_m4(mo.localToWorldMatrix, v[0], v[1], v[2], 1.0f);
+        const float wv[3] = {w.x, w.y, w.z};
+        for (int k = 0; k < 3; k++) {
+          p.lo[k] = std::min(p.lo[k], wv[k]); p.hi[k] = std::max(p.hi[k], wv[k]);
+          if (std::isfinite(wv[k])) ext = std::max(ext, std::fabs(wv[k]));
+        }
+      }
+      for (int k = 0; k < 3; k++) p.c[k] = 0.5f * p.lo[k] + 0.5f * p.hi[k];
+      B.prims.push_back(p);
+    }
+    out.mesh_first_tri[(size_t)m] = (int32_t)out.tri_slot.size();
+    if (B.prims.empty()) continue;
+    B.pad = ext * 1.52587890625e-5f + 1e-30f;
+    Box root;
+    out.mesh_root[(size_t)m] = B.build(0, (int)B.prims.size(), 1, root);
+    out.max_depth = std::max(out.max_depth, B.max_depth);
+  }
+  // leaf-ordered triangle and normal records
+  size_t nt = out.tri_slot.size();
+  out.tri_verts.assign(nt * 12, 0.0f);
+  out.tri_norms.assign(nt * 12, 0.0f);
+  for (size_t k = 0; k < nt; k++) {
+    int32_t i = out.tri_slot[k];
+    int32_t m = out.tri_mesh[k];
+    urt_MeshObject mo;
+    std::memcpy(&mo, mesh_objects + (size_t)m * sizeof(urt_MeshObject), sizeof mo);
+    urt::v3 w[3];
+    for (int j = 0; j < 3; j++) {
+      const float* v = vertices + 3 * (size_t)indices[i + j];
+      w[j] = urt::mul_m4(mo.localToWorldMatrix, v[0], v[1], v[2], 1.0f);      // RS:244-246
+    }
+    urt::v3 e1 = w[1] - w[0], e2 = w[2] - w[0];                                // RS:201-202
+    float* tv = out.tri_verts.data() + 12 * k;
+    tv[0] = w[0].x; tv[1] = w[0].y; tv[2] = w[0].z; tv[3] = urt::bits_f((uint32_t)i);
+    tv[4] = e1.x; tv[5] = e1.y; tv[6] = e1.z; tv[7] = urt::bits_f((uint32_t)m);
+    tv[8] = e2.x; tv[9] = e2.y; tv[10] = e2.z; tv[11] = 0.0f;
+    float* tn = out.tri_norms.data() + 12 * k;
+    if (normals) {
+      for (int j = 0; j < 3; j++) {
+        const float* nn = normals + 3 * (size_t)indices[i + j];              // RS:259-261
+        tn[4 * j] = nn[0]; tn[4 * j + 1] = nn[1]; tn[4 * j + 2] = nn[2];
+      }
+    }
+  }
+  return true;
+}
+
+}  // namespace urtd

@@ -1,0 +1,709 @@
+// context.cpp — implementation of the C ABI in include/urt.h.
+//
+// Stands in for the UnityEngine GPU objects RayTraceMaster.cs drives:
+//   ComputeBuffer   -> Buffer   (host copy kept; the device form is DERIVED at the next dispatch)
+//   RenderTexture   -> Texture  (RGBA32F device image)
+//   ComputeShader   -> the uniform/binding table in urt_context + dispatch of the HIP kernels
+//   Graphics.Blit   -> urt_blit / urt_blit_add
+// There is deliberately no CPU path: without a HIP device context creation fails.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+#include "../../include/urt.h"
+#include "blas_builder.h"
+#include "kernels.h"
+#include "urt_device.h"
+
+using namespace urtd;
+
+namespace {
+
+struct Buffer {
+  int count = 0, stride = 0;
+  std::vector<uint8_t> host;   // SetData copy (RM:250): the caller keeps ownership of its list
+  bool has_data = false;
+};
+
+struct Texture {
+  int w = 0, h = 0;
+  float4* dev = nullptr;
+  bool external = false;
+};
+
+enum BindSlot { B_MESHOBJECTS, B_VERTICES, B_INDICES, B_NORMALS, B_SPHERES, B_MESHBVH, B_SPHEREBVH, B_COUNT };
+const char* const kBindNames[B_COUNT] = {"_MeshObjects", "_Vertices", "_Indices", "_Normals", "_Spheres", "_MeshBVH", "_SphereBVH"};
+const int kBindStride[B_COUNT] = {URT_STRIDE_MESHOBJECT, URT_STRIDE_VEC3, URT_STRIDE_INDEX, URT_STRIDE_VEC3,
+                                  URT_STRIDE_SPHERE, URT_STRIDE_BVHNODE, URT_STRIDE_BVHNODE};
+
+std::string g_create_error;   // urt_last_error(NULL)
+
+// process-wide cache for urt_debug_build_blas / urt_debug_get_blas
+BlasResult g_debug_blas;
+
+}  // namespace
+
+struct urt_context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipStream_t own_stream = nullptr;
+  std::string err;
+  std::unordered_map<urt_handle, Buffer> buffers;
+  std::unordered_map<urt_handle, Texture> textures;
+  urt_handle next_id = 1;
+
+  urt_handle bound[B_COUNT] = {0, 0, 0, 0, 0, 0, 0};
+  urt_handle t_sky = 0, t_result = 0;
+  float c2w[16] = {0}, invp[16] = {0};
+  float pixel_off[2] = {0, 0};
+  float seed = 0;
+  int num_bounces = 0, num_rays = 0;     // shader uniforms default to 0 until SetInt (RM:780-781)
+
+  // derived device scene
+  bool scene_dirty = true;
+  DevScene ds{};
+  std::vector<void*> scene_allocs;
+  int tlas_stack = 2, blas_stack = 2;
+  float4* zero_sky = nullptr;
+
+  // wavefront queues
+  PathQueues q{};
+  size_t q_capacity = 0, counts_capacity = 0;
+
+  DevCounters* d_counters = nullptr;
+  uint64_t dispatches = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> timing;   // unresolved event pairs
+  float trace_ms = 0;
+
+  int opt_count_stats = 0, opt_time_dispatch = 0, opt_kernel_mode = 1;
+};
+
+namespace {
+
+int fail(urt_context* ctx, int code, const std::string& msg) {
+  if (ctx) ctx->err = msg; else g_create_error = msg;
+  return code;
+}
+
+#define URT_HIP(ctx, expr)                                                                         \
+  do {                                                                                             \
+    hipError_t e__ = (expr);                                                                       \
+    if (e__ != hipSuccess)                                                                         \
+      return fail(ctx, e__ == hipErrorOutOfMemory ? URT_ERR_OUT_OF_MEMORY : URT_ERR_HIP,           \
+                  std::string(#expr) + ": " + hipGetErrorString(e__));                            \
+  } while (0)
+
+#define URT_GUARD_BEGIN try {
+#define URT_GUARD_END(ctx)                                                                         \
+  } catch (const std::bad_alloc&) { return fail(ctx, URT_ERR_OUT_OF_MEMORY, "host allocation failed"); } \
+  catch (const std::exception& ex) { return fail(ctx, URT_ERR_INVALID_ARGUMENT, ex.what()); }        \
+  catch (...) { return fail(ctx, URT_ERR_INVALID_ARGUMENT, "unknown exception"); }
+
+void free_scene(urt_context* ctx) {
+  for (void* p : ctx->scene_allocs) (void)hipFree(p);
+  ctx->scene_allocs.clear();
+  ctx->ds = DevScene{};
+}
+
+template <typename T>
+int upload(urt_context* ctx, const std::vector<T>& v, const float4** out) {
+  *out = nullptr;
+  if (v.empty()) return URT_OK;
+  void* d = nullptr;
+  URT_HIP(ctx, hipMalloc(&d, v.size() * sizeof(T)));
+  ctx->scene_allocs.push_back(d);
+  URT_HIP(ctx, hipMemcpyAsync(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+  *out = (const float4*)d;
+  return URT_OK;
+}
+
+const Buffer* bound_buffer(urt_context* ctx, int slot) {
+  urt_handle h = ctx->bound[slot];
+  if (!h) return nullptr;
+  auto it = ctx->buffers.find(h);
+  if (it == ctx->buffers.end() || !it->second.has_data || it->second.count == 0) return nullptr;
+  return &it->second;
+}
+
+void pack_material(const urt_RayTraceParams& m, float* dst12) {
+  dst12[0] = m.color_albedo[0]; dst12[1] = m.color_albedo[1]; dst12[2] = m.color_albedo[2]; dst12[3] = m.smoothness;
+  dst12[4] = m.color_specular[0]; dst12[5] = m.color_specular[1]; dst12[6] = m.color_specular[2]; dst12[7] = 0;
+  dst12[8] = m.emission[0]; dst12[9] = m.emission[1]; dst12[10] = m.emission[2]; dst12[11] = 0;
+}
+
+int heap_levels(int n) { int l = 0; while (n > 0) { l++; n >>= 1; } return l; }   // floor(log2 n) + 1
+
+void pack_tlas(const Buffer* b, std::vector<float>& out) {
+  out.clear();
+  if (!b) return;
+  out.resize((size_t)b->count * 8);
+  for (int i = 0; i < b->count; i++) {
+    urt_BVHNode nd;
+    std::memcpy(&nd, b->host.data() + (size_t)i * URT_STRIDE_BVHNODE, sizeof nd);
+    float* o = out.data() + (size_t)i * 8;
+    o[0] = nd.vmin[0]; o[1] = nd.vmin[1]; o[2] = nd.vmin[2]; std::memcpy(&o[3], &nd.index, 4);
+    o[4] = nd.vmax[0]; o[5] = nd.vmax[1]; o[6] = nd.vmax[2]; o[7] = 0;
+  }
+}
+
+// Derive the device scene from the bound ComputeBuffers (runs at the first dispatch after a change;
+// the reference pays the equivalent in RebuildTrees -> SetData, RM:725-746).
+int prepare_scene(urt_context* ctx) {
+  free_scene(ctx);
+  DevScene& S = ctx->ds;
+  const Buffer* bm = bound_buffer(ctx, B_MESHOBJECTS);
+  const Buffer* bv = bound_buffer(ctx, B_VERTICES);
+  const Buffer* bi = bound_buffer(ctx, B_INDICES);
+  const Buffer* bn = bound_buffer(ctx, B_NORMALS);
+  const Buffer* bs = bound_buffer(ctx, B_SPHERES);
+  const Buffer* bmt = bound_buffer(ctx, B_MESHBVH);
+  const Buffer* bst = bound_buffer(ctx, B_SPHEREBVH);
+
+  int rc;
+  // meshes
+  int n_meshes = bm ? bm->count : 0;
+  BlasResult blas;
+  if (n_meshes > 0) {
+    std::string err;
+    if (!build_blas(bm->host.data(), n_meshes, bv ? (const float*)bv->host.data() : nullptr, bv ? bv->count : 0,
+                    bi ? (const int32_t*)bi->host.data() : nullptr, bi ? bi->count : 0,
+                    bn ? (const float*)bn->host.data() : nullptr, bn ? bn->count : 0, blas, err))
+      return fail(ctx, URT_ERR_SCENE, err);
+    std::vector<float> mats((size_t)n_meshes * 12);
+    for (int m = 0; m < n_meshes; m++) {
+      urt_MeshObject mo;
+      std::memcpy(&mo, bm->host.data() + (size_t)m * URT_STRIDE_MESHOBJECT, sizeof mo);
+      pack_material(mo.lighting, mats.data() + (size_t)m * 12);
+    }
+    const float4* p;
+    if ((rc = upload(ctx, mats, &p))) return rc; S.mesh_mat = p;
+    if ((rc = upload(ctx, blas.mesh_root, &p))) return rc; S.mesh_root = (const int32_t*)p;
+    if ((rc = upload(ctx, blas.nodes, &p))) return rc; S.blas_nodes = p;
+    if ((rc = upload(ctx, blas.tri_verts, &p))) return rc; S.tri_verts = p;
+    if ((rc = upload(ctx, blas.tri_norms, &p))) return rc; S.tri_norms = p;
+  }
+  S.n_meshes = n_meshes;
+  // spheres
+  int n_spheres = bs ? bs->count : 0;
+  if (n_spheres > 0) {
+    std::vector<float> pr((size_t)n_spheres * 4), mats((size_t)n_spheres * 12);
+    for (int i = 0; i < n_spheres; i++) {
+      urt_Sphere sp;
+      std::memcpy(&sp, bs->host.data() + (size_t)i * URT_STRIDE_SPHERE, sizeof sp);
+      pr[4 * (size_t)i] = sp.position[0]; pr[4 * (size_t)i + 1] = sp.position[1]; pr[4 * (size_t)i + 2] = sp.position[2];
+      pr[4 * (size_t)i + 3] = sp.radius;
+      pack_material(sp.lighting, mats.data() + (size_t)i * 12);
+    }
+    const float4* p;
+    if ((rc = upload(ctx, pr, &p))) return rc; S.sphere_pr = p;
+    if ((rc = upload(ctx, mats, &p))) return rc; S.sphere_mat = p;
+  }
+  S.n_spheres = n_spheres;
+  // object-level BVHs
+  std::vector<float> t;
+  const float4* p;
+  pack_tlas(bmt, t);
+  if ((rc = upload(ctx, t, &p))) return rc; S.mesh_tlas = p; S.n_mesh_tlas = bmt ? bmt->count : 0;
+  pack_tlas(bst, t);
+  if ((rc = upload(ctx, t, &p))) return rc; S.sphere_tlas = p; S.n_sphere_tlas = bst ? bst->count : 0;
+
+  // traversal stack budgets (per lane, LDS)
+  int lv = std::max(heap_levels(S.n_mesh_tlas), heap_levels(S.n_sphere_tlas));
+  if (lv + 1 > 32)
+    return fail(ctx, URT_ERR_SCENE, "object-level BVH deeper than the reference's 32-entry traversal stack (RS:73-74)");
+  ctx->tlas_stack = std::max(2, lv + 1);
+  ctx->blas_stack = std::max(2, blas.max_depth + 1);
+  if ((size_t)(ctx->tlas_stack + ctx->blas_stack) * 64 * 4 * sizeof(int) > 64 * 1024)
+    return fail(ctx, URT_ERR_SCENE, "traversal stacks exceed the 64 KiB LDS budget per workgroup");
+  ctx->scene_dirty = false;
+  return URT_OK;
+}
+
+int ensure_queues(urt_context* ctx, size_t n_paths, size_t n_counts) {
+  if (n_paths > ctx->q_capacity) {
+    for (int a = 0; a < 2; a++)
+      for (int r = 0; r < 4; r++) {
+        if (ctx->q.s[a][r]) (void)hipFree(ctx->q.s[a][r]);
+        ctx->q.s[a][r] = nullptr;
+      }
+    ctx->q_capacity = 0;
+    for (int a = 0; a < 2; a++)
+      for (int r = 0; r < 4; r++) URT_HIP(ctx, hipMalloc((void**)&ctx->q.s[a][r], n_paths * sizeof(float4)));
+    ctx->q_capacity = n_paths;
+  }
+  if (n_counts > ctx->counts_capacity) {
+    if (ctx->q.counts) (void)hipFree(ctx->q.counts);
+    ctx->q.counts = nullptr; ctx->counts_capacity = 0;
+    URT_HIP(ctx, hipMalloc((void**)&ctx->q.counts, n_counts * sizeof(unsigned int)));
+    ctx->counts_capacity = n_counts;
+  }
+  return URT_OK;
+}
+
+Texture* find_texture(urt_context* ctx, urt_handle h) {
+  auto it = ctx->textures.find(h);
+  return it == ctx->textures.end() ? nullptr : &it->second;
+}
+
+int resolve_timing(urt_context* ctx) {
+  for (auto& pr : ctx->timing) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) ctx->trace_ms += ms;
+    (void)hipEventDestroy(pr.first);
+    (void)hipEventDestroy(pr.second);
+  }
+  ctx->timing.clear();
+  return URT_OK;
+}
+
+int do_dispatch(urt_context* ctx, int kernel, int gx, int gy, int gz, int first_row, int row_stride) {
+  if (kernel != 0) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "kernel index must be 0 (CSMain)");
+  if (gx < 0 || gy < 0 || gz < 0 || first_row < 0 || row_stride < 1)
+    return fail(ctx, URT_ERR_INVALID_ARGUMENT, "negative thread-group count or bad strip arguments");
+  Texture* res = find_texture(ctx, ctx->t_result);
+  if (!res) return fail(ctx, URT_ERR_UNBOUND, "Dispatch: no texture bound to \"Result\" (RM:803)");
+  if (res->w > 65535 || res->h > 65535) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "Result larger than 65535 pixels per side");
+  URT_HIP(ctx, hipSetDevice(ctx->device));
+  if (ctx->scene_dirty) { int rc = prepare_scene(ctx); if (rc) return rc; }
+  ctx->dispatches++;
+  if (gx == 0 || gy == 0 || gz == 0) return URT_OK;
+
+  DevScene S = ctx->ds;
+  Texture* sky = find_texture(ctx, ctx->t_sky);
+  if (sky) { S.sky = sky->dev; S.sky_w = sky->w; S.sky_h = sky->h; }
+  else {     // an unbound SRV reads zeros
+    if (!ctx->zero_sky) {
+      URT_HIP(ctx, hipMalloc((void**)&ctx->zero_sky, sizeof(float4)));
+      URT_HIP(ctx, hipMemsetAsync(ctx->zero_sky, 0, sizeof(float4), ctx->stream));
+    }
+    S.sky = ctx->zero_sky; S.sky_w = 1; S.sky_h = 1;
+  }
+
+  FrameParams P{};
+  std::memcpy(P.c2w, ctx->c2w, sizeof P.c2w);
+  std::memcpy(P.invp, ctx->invp, sizeof P.invp);
+  P.pixel_off_x = ctx->pixel_off[0]; P.pixel_off_y = ctx->pixel_off[1];
+  P.seed = ctx->seed;
+  P.num_bounces = ctx->num_bounces; P.num_rays = ctx->num_rays;
+  P.width = res->w; P.height = res->h;
+  long rw = std::min<long>((long)gx * 8, res->w), rh = std::min<long>((long)gy * 8, res->h);
+  P.region_w = (int)rw; P.region_h = (int)rh;
+  P.tiles_x = (P.region_w + 7) / 8;
+  int group_rows = (P.region_h + 7) / 8;
+  P.first_group_row = first_row; P.row_stride = row_stride;
+  P.n_strips = first_row < group_rows ? (group_rows - first_row + row_stride - 1) / row_stride : 0;
+  P.tlas_stack = ctx->tlas_stack; P.blas_stack = ctx->blas_stack;
+  if (P.n_strips == 0 || P.tiles_x == 0) return URT_OK;
+
+  bool wavefront = ctx->opt_kernel_mode == 1 && P.num_bounces > 0 && P.num_rays > 0;
+  if (wavefront) {
+    size_t n_paths = (size_t)P.tiles_x * 64 * (size_t)P.n_strips;
+    int rc = ensure_queues(ctx, n_paths, (size_t)P.num_rays * (size_t)(P.num_bounces + 1));
+    if (rc) return rc;
+  }
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (ctx->opt_time_dispatch) {
+    URT_HIP(ctx, hipEventCreate(&e0));
+    URT_HIP(ctx, hipEventCreate(&e1));
+    URT_HIP(ctx, hipEventRecord(e0, ctx->stream));
+  }
+  hipError_t le = wavefront ? launch_wavefront(S, P, ctx->q, res->dev, ctx->d_counters, ctx->opt_count_stats != 0, ctx->stream)
+                            : launch_mega(S, P, res->dev, ctx->d_counters, ctx->opt_count_stats != 0, ctx->stream);
+  if (ctx->opt_time_dispatch) {
+    (void)hipEventRecord(e1, ctx->stream);
+    ctx->timing.emplace_back(e0, e1);
+  }
+  if (le != hipSuccess) return fail(ctx, URT_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(le));
+  return URT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int urt_abi_version(void) { return 1; }
+
+int urt_device_count(int* out_count) {
+  if (!out_count) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "out_count is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) { *out_count = 0; return fail(nullptr, URT_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e)); }
+  *out_count = n;
+  return URT_OK;
+}
+
+int urt_context_create(int device, urt_context** out_ctx) {
+  if (!out_ctx) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "out_ctx is NULL");
+  *out_ctx = nullptr;
+  URT_GUARD_BEGIN
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(nullptr, URT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+  if (device < 0 || device >= n) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "device ordinal out of range");
+  URT_HIP(nullptr, hipSetDevice(device));
+  urt_context* ctx = new urt_context();
+  ctx->device = device;
+  e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+  if (e != hipSuccess) { delete ctx; return fail(nullptr, URT_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
+  ctx->stream = ctx->own_stream;
+  e = hipMalloc((void**)&ctx->d_counters, sizeof(DevCounters));
+  if (e == hipSuccess) e = hipMemset(ctx->d_counters, 0, sizeof(DevCounters));
+  if (e != hipSuccess) { (void)hipStreamDestroy(ctx->own_stream); delete ctx; return fail(nullptr, URT_ERR_HIP, std::string("counter allocation: ") + hipGetErrorString(e)); }
+  *out_ctx = ctx;
+  return URT_OK;
+  URT_GUARD_END(nullptr)
+}
+
+int urt_context_destroy(urt_context* ctx) {
+  if (!ctx) return URT_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  resolve_timing(ctx);
+  free_scene(ctx);
+  for (auto& kv : ctx->textures) if (!kv.second.external && kv.second.dev) (void)hipFree(kv.second.dev);
+  for (int a = 0; a < 2; a++) for (int r = 0; r < 4; r++) if (ctx->q.s[a][r]) (void)hipFree(ctx->q.s[a][r]);
+  if (ctx->q.counts) (void)hipFree(ctx->q.counts);
+  if (ctx->zero_sky) (void)hipFree(ctx->zero_sky);
+  if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+  return URT_OK;
+}
+
+const char* urt_last_error(urt_context* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int urt_context_set_stream(urt_context* ctx, void* hip_stream) {
+  if (!ctx) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  URT_HIP(ctx, hipSetDevice(ctx->device));
+  URT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  return URT_OK;
+}
+
+int urt_synchronize(urt_context* ctx) {
+  if (!ctx) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  URT_HIP(ctx, hipSetDevice(ctx->device));
+  URT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return URT_OK;
+}
+
+/* ---- ComputeBuffer ---- */
+int urt_buffer_create(urt_context* ctx, int count, int stride, urt_handle* out_buffer) {
+  if (!ctx) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  if (!out_buffer) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "out_buffer is NULL");
+  // Unity: "ComputeBuffer count/stride must be greater than 0" and stride a multiple of 4
+  if (count <= 0 || stride <= 0 || (stride & 3)) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "ComputeBuffer: count and stride must be > 0 and stride a multiple of 4");
+  URT_GUARD_BEGIN
+  Buffer b; b.count = count; b.stride = stride;
+  b.host.assign((size_t)count * (size_t)stride, 0);
+  urt_handle h = ctx->next_id++;
+  ctx->buffers.emplace(h, std::move(b));
+  *out_buffer = h;
+  return URT_OK;
+  URT_GUARD_END(ctx)
+}
+
+int urt_buffer_set_data(urt_context* ctx, urt_handle buffer, const void* data, int count) {
+  if (!ctx) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  auto it = ctx->buffers.find(buffer);
+  if (it == ctx->buffers.end()) return fail(ctx, URT_ERR_INVALID_HANDLE, "SetData: unknown buffer handle");
+  Buffer& b = it->second;
+  if (count < 0 || count > b.count) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "SetData: more elements than the buffer holds");
+  if (count > 0 && !data) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "SetData: data is NULL");
+  if (count > 0) std::memcpy(b.host.data(), data, (size_t)count * (size_t)b.stride);
+  b.has_data = true;
+  for (int s = 0; s < B_COUNT; s++) if (ctx->bound[s] == buffer) ctx->scene_dirty = true;
+  return URT_OK;
+}
+
+int urt_buffer_get_info(urt_context* ctx, urt_handle buffer, int* out_count, int* out_stride) {
+  if (!ctx) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  auto it = ctx->buffers.find(buffer);
+  if (it == ctx->buffers.end()) return fail(ctx, URT_ERR_INVALID_HANDLE, "unknown buffer handle");
+  if (out_count) *out_count = it->second.count;
+  if (out_stride) *out_stride = it->second.stride;
+  return URT_OK;
+}
+
+int urt_buffer_release(urt_context* ctx, urt_handle buffer) {
+  if (!ctx) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  auto it = ctx->buffers.find(buffer);
+  if (it == ctx->buffers.end()) return fail(ctx, URT_ERR_INVALID_HANDLE, "Release: unknown buffer handle");
+  for (int s = 0; s < B_COUNT; s++) if (ctx->bound[s] == buffer) { ctx->bound[s] = 0; ctx->scene_dirty = true; }
+  ctx->buffers.erase(it);
+  return URT_OK;
+}
+
+/* ---- textures ---- */
+static int texture_create_impl(urt_context* ctx, int width, int height, void* ext, urt_handle* out_texture) {
+  if (!ctx) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  if (!out_texture) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "out_texture is NULL");
+  if (width <= 0 || height <= 0) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "texture size must be positive");
+  URT_GUARD_BEGIN
+  URT_HIP(ctx, hipSetDevice(ctx->device));
+  Texture t; t.w = width; t.h = height;
+  size_t bytes = (size_t)width * (size_t)height * sizeof(float4);
+  if (ext) { t.dev = (float4*)ext; t.external = true; }
+  else {
+    URT_HIP(ctx, hipMalloc((void**)&t.dev, bytes));
+    hipError_t e = hipMemsetAsync(t.dev, 0, bytes, ctx->stream);
+    if (e != hipSuccess) { (void)hipFree(t.dev); return fail(ctx, URT_ERR_HIP, std::string("hipMemsetAsync: ") + hipGetErrorString(e)); }
+  }
+  urt_handle h = ctx->next_id++;
+  ctx->textures.emplace(h, t);
+  *out_texture = h;
+  return URT_OK;
+  URT_GUARD_END(ctx)
+}
+
+int urt_texture_create(urt_context* ctx, int width, int height, urt_handle* out_texture) {
+  return texture_create_impl(ctx, width, height, nullptr, out_texture);
+}
+
+int urt_texture_create_external(urt_context* ctx, int width, int height, void* device_ptr, urt_handle* out_texture) {
+  if (ctx && !device_ptr) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "device_ptr is NULL");
+  return texture_create_impl(ctx, width, height, device_ptr, out_texture);
+}
+
+int urt_texture_set_pixels(urt_context* ctx, urt_handle texture, const float* rgba) {
+  if (!ctx) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  Texture* t = find_texture(ctx, texture);
+  if (!t) return fail(ctx, URT_ERR_INVALID_HANDLE, "unknown texture handle");
+  if (!rgba) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "rgba is NULL");
+  URT_HIP(ctx, hipSetDevice(ctx->device));
+  URT_HIP(ctx, hipMemcpyAsync(t->dev, rgba, (size_t)t->w * t->h * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+  URT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return URT_OK;
+}
+
+int urt_texture_get_pixels(urt_context* ctx, urt_handle texture, float* rgba) {
+  if (!ctx) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  Texture* t = find_texture(ctx, texture);
+  if (!t) return fail(ctx, URT_ERR_INVALID_HANDLE, "unknown texture handle");
+  if (!rgba) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "rgba is NULL");
+  URT_HIP(ctx, hipSetDevice(ctx->device));
+  URT_HIP(ctx, hipMemcpyAsync(rgba, t->dev, (size_t)t->w * t->h * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+  URT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return URT_OK;
+}
+
+int urt_texture_get_info(urt_context* ctx, urt_handle texture, int* out_width, int* out_height, void** out_device_ptr) {
+  if (!ctx) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  Texture* t = find_texture(ctx, texture);
+  if (!t) return fail(ctx, URT_ERR_INVALID_HANDLE, "unknown texture handle");
+  if (out_width) *out_width = t->w;
+  if (out_height) *out_height = t->h;
+  if (out_device_ptr) *out_device_ptr = t->dev;
+  return URT_OK;
+}
+
+int urt_texture_release(urt_context* ctx, urt_handle texture) {
+  if (!ctx) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  auto it = ctx->textures.find(texture);
+  if (it == ctx->textures.end()) return fail(ctx, URT_ERR_INVALID_HANDLE, "Release: unknown texture handle");
+  URT_HIP(ctx, hipSetDevice(ctx->device));
+  URT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (!it->second.external && it->second.dev) (void)hipFree(it->second.dev);
+  if (ctx->t_sky == texture) ctx->t_sky = 0;
+  if (ctx->t_result == texture) ctx->t_result = 0;
+  ctx->textures.erase(it);
+  return URT_OK;
+}
+
+/* ---- shader uniforms and bindings ---- */
+int urt_shader_set_buffer(urt_context* ctx, int kernel, const char* name, urt_handle buffer) {
+  if (!ctx) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  if (kernel != 0 || !name) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "SetBuffer: kernel must be 0 and name non-NULL");
+  for (int s = 0; s < B_COUNT; s++) {
+    if (std::strcmp(name, kBindNames[s]) != 0) continue;
+    if (buffer) {
+      auto it = ctx->buffers.find(buffer);
+      if (it == ctx->buffers.end()) return fail(ctx, URT_ERR_INVALID_HANDLE, "SetBuffer: unknown buffer handle");
+      if (it->second.stride != kBindStride[s])
+        return fail(ctx, URT_ERR_LAYOUT, std::string("SetBuffer(") + name + "): stride " + std::to_string(it->second.stride) +
+                                             " != " + std::to_string(kBindStride[s]) + " (RM:738-745)");
+    }
+    if (ctx->bound[s] != buffer) { ctx->bound[s] = buffer; }
+    ctx->scene_dirty = true;
+    return URT_OK;
+  }
+  return fail(ctx, URT_ERR_INVALID_ARGUMENT, std::string("SetBuffer: kernel CSMain has no buffer named ") + name);
+}
+
+int urt_shader_set_texture(urt_context* ctx, int kernel, const char* name, urt_handle texture) {
+  if (!ctx) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  if (kernel != 0 || !name) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "SetTexture: kernel must be 0 and name non-NULL");
+  if (texture && !find_texture(ctx, texture)) return fail(ctx, URT_ERR_INVALID_HANDLE, "SetTexture: unknown texture handle");
+  if (std::strcmp(name, "_SkyboxTexture") == 0) { ctx->t_sky = texture; return URT_OK; }
+  if (std::strcmp(name, "Result") == 0) { ctx->t_result = texture; return URT_OK; }
+  return fail(ctx, URT_ERR_INVALID_ARGUMENT, std::string("SetTexture: kernel CSMain has no texture named ") + name);
+}
+
+int urt_shader_set_matrix(urt_context* ctx, const char* name, const float* m16) {
+  if (!ctx) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  if (!name || !m16) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "SetMatrix: NULL argument");
+  if (std::strcmp(name, "_CameraToWorld") == 0) std::memcpy(ctx->c2w, m16, sizeof ctx->c2w);
+  else if (std::strcmp(name, "_CameraInverseProjection") == 0) std::memcpy(ctx->invp, m16, sizeof ctx->invp);
+  return URT_OK;   // undeclared names are ignored, as Unity does
+}
+
+int urt_shader_set_vector(urt_context* ctx, const char* name, const float* v4) {
+  if (!ctx) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  if (!name || !v4) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "SetVector: NULL argument");
+  if (std::strcmp(name, "_PixelOffset") == 0) { ctx->pixel_off[0] = v4[0]; ctx->pixel_off[1] = v4[1]; }
+  return URT_OK;
+}
+
+int urt_shader_set_float(urt_context* ctx, const char* name, float value) {
+  if (!ctx) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  if (!name) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "SetFloat: NULL name");
+  if (std::strcmp(name, "_Seed") == 0) ctx->seed = value;
+  return URT_OK;
+}
+
+int urt_shader_set_int(urt_context* ctx, const char* name, int value) {
+  if (!ctx) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  if (!name) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "SetInt: NULL name");
+  if (std::strcmp(name, "_numBounces") == 0) ctx->num_bounces = value;
+  else if (std::strcmp(name, "_numRays") == 0) ctx->num_rays = value;
+  // "_MeshBVH_len" / "_SphereBVH_len": static const in the shader (RS:73-74) — accepted, no effect
+  return URT_OK;
+}
+
+int urt_shader_dispatch(urt_context* ctx, int kernel, int groups_x, int groups_y, int groups_z) {
+  if (!ctx) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  URT_GUARD_BEGIN
+  return do_dispatch(ctx, kernel, groups_x, groups_y, groups_z, 0, 1);
+  URT_GUARD_END(ctx)
+}
+
+int urt_shader_dispatch_rows(urt_context* ctx, int kernel, int groups_x, int groups_y, int groups_z, int first_group_row,
+                             int row_stride) {
+  if (!ctx) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  URT_GUARD_BEGIN
+  return do_dispatch(ctx, kernel, groups_x, groups_y, groups_z, first_group_row, row_stride);
+  URT_GUARD_END(ctx)
+}
+
+/* ---- blits ---- */
+int urt_blit_add(urt_context* ctx, urt_handle src, urt_handle dst, float sample) {
+  if (!ctx) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  Texture* s = find_texture(ctx, src);
+  Texture* d = find_texture(ctx, dst);
+  if (!s || !d) return fail(ctx, URT_ERR_INVALID_HANDLE, "Blit: unknown texture handle");
+  if (s->w != d->w || s->h != d->h) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "Blit: source and destination sizes differ");
+  URT_HIP(ctx, hipSetDevice(ctx->device));
+  URT_HIP(ctx, launch_blit_add(s->dev, d->dev, (size_t)s->w * s->h, sample, ctx->stream));
+  return URT_OK;
+}
+
+int urt_blit(urt_context* ctx, urt_handle src, urt_handle dst) {
+  if (!ctx) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  Texture* s = find_texture(ctx, src);
+  Texture* d = find_texture(ctx, dst);
+  if (!s || !d) return fail(ctx, URT_ERR_INVALID_HANDLE, "Blit: unknown texture handle");
+  if (s->w != d->w || s->h != d->h) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "Blit: source and destination sizes differ");
+  URT_HIP(ctx, hipSetDevice(ctx->device));
+  URT_HIP(ctx, hipMemcpyAsync(d->dev, s->dev, (size_t)s->w * s->h * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
+  return URT_OK;
+}
+
+static int pack_impl(urt_context* ctx, urt_handle texture, int first_group_row, int row_stride, void* dense, bool to_dense,
+                     uint64_t* out_bytes) {
+  if (!ctx) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  Texture* t = find_texture(ctx, texture);
+  if (!t) return fail(ctx, URT_ERR_INVALID_HANDLE, "unknown texture handle");
+  if (first_group_row < 0 || row_stride < 1) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "bad strip arguments");
+  int group_rows = (t->h + 7) / 8;
+  int n_strips = first_group_row < group_rows ? (group_rows - first_group_row + row_stride - 1) / row_stride : 0;
+  if (out_bytes) *out_bytes = (uint64_t)n_strips * 8u * (uint64_t)t->w * sizeof(float4);
+  if (!dense) return URT_OK;   // size query
+  URT_HIP(ctx, hipSetDevice(ctx->device));
+  URT_HIP(ctx, launch_pack_rows(t->dev, (float4*)dense, t->w, t->h, first_group_row, row_stride, n_strips, to_dense, ctx->stream));
+  return URT_OK;
+}
+
+int urt_texture_pack_rows(urt_context* ctx, urt_handle texture, int first_group_row, int row_stride, void* device_dst,
+                          uint64_t* out_bytes) {
+  return pack_impl(ctx, texture, first_group_row, row_stride, device_dst, true, out_bytes);
+}
+
+int urt_texture_unpack_rows(urt_context* ctx, urt_handle texture, int first_group_row, int row_stride, const void* device_src) {
+  if (ctx && !device_src) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "device_src is NULL");
+  return pack_impl(ctx, texture, first_group_row, row_stride, const_cast<void*>(device_src), false, nullptr);
+}
+
+/* ---- measurement ---- */
+int urt_set_option(urt_context* ctx, const char* name, int value) {
+  if (!ctx) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  if (!name) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "option name is NULL");
+  if (std::strcmp(name, "count_stats") == 0) ctx->opt_count_stats = value ? 1 : 0;
+  else if (std::strcmp(name, "time_dispatch") == 0) ctx->opt_time_dispatch = value ? 1 : 0;
+  else if (std::strcmp(name, "kernel_mode") == 0) {
+    if (value != 0 && value != 1) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "kernel_mode must be 0 or 1");
+    ctx->opt_kernel_mode = value;
+  } else return fail(ctx, URT_ERR_INVALID_ARGUMENT, std::string("unknown option ") + name);
+  return URT_OK;
+}
+
+int urt_get_counters(urt_context* ctx, urt_counters* out) {
+  if (!ctx) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  if (!out) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "out is NULL");
+  URT_HIP(ctx, hipSetDevice(ctx->device));
+  URT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  resolve_timing(ctx);
+  DevCounters dc;
+  URT_HIP(ctx, hipMemcpy(&dc, ctx->d_counters, sizeof dc, hipMemcpyDeviceToHost));
+  std::memset(out, 0, sizeof *out);
+  out->rays = dc.rays; out->tlas_nodes = dc.tlas_nodes; out->blas_nodes = dc.blas_nodes; out->tri_tests = dc.tri_tests;
+  out->sphere_tests = dc.sphere_tests; out->hit_tri = dc.hit_tri; out->hit_sphere = dc.hit_sphere;
+  out->hit_ground = dc.hit_ground; out->hit_sky = dc.hit_sky; out->pixels = dc.pixels;
+  out->dispatches = ctx->dispatches;
+  out->trace_ms = ctx->trace_ms;
+  return URT_OK;
+}
+
+int urt_reset_counters(urt_context* ctx) {
+  if (!ctx) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  URT_HIP(ctx, hipSetDevice(ctx->device));
+  URT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  resolve_timing(ctx);
+  URT_HIP(ctx, hipMemset(ctx->d_counters, 0, sizeof(DevCounters)));
+  ctx->dispatches = 0;
+  ctx->trace_ms = 0;
+  return URT_OK;
+}
+
+/* ---- introspection ---- */
+int urt_debug_build_blas(const void* mesh_objects, int n_meshes, const float* vertices, int n_vertices, const int32_t* indices,
+                         int n_indices, int* out_n_nodes, int* out_n_tris, int* out_max_depth) {
+  URT_GUARD_BEGIN
+  if (n_meshes < 0 || (n_meshes > 0 && !mesh_objects)) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "mesh_objects is NULL");
+  std::string err;
+  if (!build_blas((const uint8_t*)mesh_objects, n_meshes, vertices, n_vertices, indices, n_indices, nullptr, 0, g_debug_blas, err))
+    return fail(nullptr, URT_ERR_SCENE, err);
+  if (out_n_nodes) *out_n_nodes = (int)(g_debug_blas.nodes.size() / kBlasNodeFloats);
+  if (out_n_tris) *out_n_tris = (int)g_debug_blas.tri_slot.size();
+  if (out_max_depth) *out_max_depth = g_debug_blas.max_depth;
+  return URT_OK;
+  URT_GUARD_END(nullptr)
+}
+
+int urt_debug_get_blas(float* nodes, int32_t* tri_index, int32_t* mesh_root, int32_t* mesh_first_tri) {
+  const BlasResult& b = g_debug_blas;
+  if (nodes && !b.nodes.empty()) std::memcpy(nodes, b.nodes.data(), b.nodes.size() * sizeof(float));
+  if (tri_index && !b.tri_slot.empty()) std::memcpy(tri_index, b.tri_slot.data(), b.tri_slot.size() * sizeof(int32_t));
+  if (mesh_root && !b.mesh_root.empty()) std::memcpy(mesh_root, b.mesh_root.data(), b.mesh_root.size() * sizeof(int32_t));
+  if (mesh_first_tri && !b.mesh_first_tri.empty()) std::memcpy(mesh_first_tri, b.mesh_first_tri.data(), b.mesh_first_tri.size() * sizeof(int32_t));
+  return URT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,19 @@
+// kernels.h — host-callable launchers of the HIP kernels in kernels.hip
+#pragma once
+#include <hip/hip_runtime.h>
+#include "urt_device.h"
+
+namespace urtd {
+
+// mode 0: whole CSMain per thread (RS:431-469)
+hipError_t launch_mega(const DevScene& S, const FrameParams& P, float4* result, DevCounters* ctr, bool count, hipStream_t st);
+// mode 1: generate + one launch per bounce over compacted path queues
+hipError_t launch_wavefront(const DevScene& S, const FrameParams& P, const PathQueues& Q, float4* result, DevCounters* ctr,
+                            bool count, hipStream_t st);
+// AdditionShader blend (AS:9,39-41)
+hipError_t launch_blit_add(const float4* src, float4* dst, size_t n_pixels, float sample, hipStream_t st);
+// strips <-> dense buffer
+hipError_t launch_pack_rows(float4* img, float4* dense, int width, int height, int first_group_row, int row_stride,
+                            int n_strips, bool to_dense, hipStream_t st);
+
+}  // namespace urtd

@@ -1,0 +1,601 @@
+// kernels.hip — hand-written HIP kernels for gfx950 (MI355X, CDNA4): the path-tracing hot path of
+// RemyMuj/UnityRayTracer re-designed for 64-wide wavefronts.
+//
+// Reference being replaced: Assets/Shaders/RayTraceShader.compute ("RS", kernel CSMain RS:431-469 and
+// everything it calls) and Assets/Shaders/AdditionShader.shader ("AS", AS:9,39-41).
+//
+// This is not a translation of the HLSL:
+//  * the reference intersects EVERY triangle of a mesh per ray (RS:243); here each MeshObject has a
+//    triangle BVH over pre-transformed world-space triangles (v0, e1, e2 as float4 records), traversed
+//    with a per-lane stack that lives in LDS ([entry][lane] layout: conflict-free, no scratch);
+//  * the reference carries a 68-byte RayHit with the material through traversal (RS:36-41); here the
+//    traversal carries (t, kind, id, u, v) and normals/material are fetched once per closest hit;
+//  * the reference is one thread per pixel for all bounces; the default mode here is a wavefront
+//    pipeline: one kernel launch per bounce over a COMPACTED queue of live paths (wave64 ballot +
+//    prefix popcount + one atomic per wave), so lanes whose paths ended on the sky do not idle;
+//  * pixel -> lane mapping is one 8x8 tile per wave (the reference's group shape) with an XCD-aware
+//    block order so that one XCD's L2 serves one contiguous band of the image.
+// Arithmetic is the normative float32 of include/urt_math.h, compiled with -ffp-contract=off; results
+// are bit-identical to the scalar restatement in oracle/ (tests/test_gpu_parity.py).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/urt_math.h"
+#include "urt_device.h"
+#include "kernels.h"
+
+using namespace urt;
+using namespace urtd;
+
+namespace {
+
+struct LocalCounters {
+  unsigned int rays = 0, tlas_nodes = 0, blas_nodes = 0, tri_tests = 0, sphere_tests = 0;
+  unsigned int hit_tri = 0, hit_sphere = 0, hit_ground = 0, hit_sky = 0, pixels = 0;
+};
+
+struct HitRec {
+  float t;     // distance, +inf = miss
+  int kind;    // 0 none, 1 ground plane, 2 sphere, 3 triangle
+  int id;      // sphere index, or leaf-order triangle slot
+  float u, v;  // barycentrics of a triangle hit
+};
+
+__device__ __forceinline__ v3 xyz(float4 q) { return mk3(q.x, q.y, q.z); }
+__device__ __forceinline__ int as_int(float f) { return __builtin_bit_cast(int, f); }
+__device__ __forceinline__ float as_float(int i) { return __builtin_bit_cast(float, i); }
+
+// ---------------------------------------------------------------------------------------------------
+// object-level BVH (the reference's implicit heap) — RS:271-291 slab test, RS:294-361 traversal
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool tlas_slab(float4 a, float4 b, v3 o, v3 rcp) {
+  if (a.x == b.x && a.y == b.y && a.z == b.z) return false;      // RS:273 empty node
+  float t_min = -kFLOAT_MAX, t_max = kFLOAT_MAX;
+  float t1 = (a.x - o.x) * rcp.x, t2 = (b.x - o.x) * rcp.x;
+  t_min = f_max(t_min, f_min(t1, t2)); t_max = f_min(t_max, f_max(t1, t2));
+  t1 = (a.y - o.y) * rcp.y; t2 = (b.y - o.y) * rcp.y;
+  t_min = f_max(t_min, f_min(t1, t2)); t_max = f_min(t_max, f_max(t1, t2));
+  t1 = (a.z - o.z) * rcp.z; t2 = (b.z - o.z) * rcp.z;
+  t_min = f_max(t_min, f_min(t1, t2)); t_max = f_min(t_max, f_max(t1, t2));
+  return t_max >= t_min;
+}
+
+// RS:175-196 without the material copy (fetched at shading time)
+template <bool COUNT>
+__device__ __forceinline__ void intersect_sphere(const DevScene& S, int idx, v3 o, v3 d, HitRec& best, LocalCounters& lc) {
+  if (COUNT) lc.sphere_tests++;
+  float4 pr = S.sphere_pr[idx];
+  v3 dd = o - xyz(pr);
+  float p1 = -dot(d, dd);
+  float p2sqr = p1 * p1 - dot(dd, dd) + pr.w * pr.w;
+  if (p2sqr < 0) return;
+  float p2 = f_sqrt(p2sqr);
+  float t = p1 - p2 > 0 ? p1 - p2 : p1 + p2;
+  if (t > 0 && t < best.t) { best.t = t; best.kind = 2; best.id = idx; }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// triangle BVH traversal for one MeshObject.  Replaces the brute-force loop RS:243-266 and returns
+// the same winner: minimum t, ties inside one call going to the lowest index slot (A.4).
+// Stack: LDS, entry e of this lane at stk[e * 64].
+// ---------------------------------------------------------------------------------------------------
+template <bool COUNT>
+__device__ __forceinline__ void intersect_mesh(const DevScene& S, int32_t root, v3 o, v3 d, HitRec& best,
+                                               int* stk, LocalCounters& lc) {
+  if (root == kEmptyMeshRoot) return;
+  // per-ray slab constants: boxes are widened by pad = 2^-16 * max|origin| on top of the build-time pad
+  float pad = f_max(f_max(f_abs(o.x), f_abs(o.y)), f_abs(o.z)) * 1.52587890625e-5f;
+  v3 idir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  v3 nop = mk3(-((o.x + pad) * idir.x), -((o.y + pad) * idir.y), -((o.z + pad) * idir.z));
+  v3 nom = mk3(-((o.x - pad) * idir.x), -((o.y - pad) * idir.y), -((o.z - pad) * idir.z));
+  int best_i = -1;          // index slot of a hit made in THIS call (enables the equal-t tie rule)
+  int sp = 0;
+  int32_t cur = root;
+  for (;;) {
+    if (cur >= 0) {
+      if (COUNT) lc.blas_nodes++;
+      const float4* n = S.blas_nodes + 4 * (size_t)cur;
+      float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
+      float tb = best.t;
+      // child 0: min (q0.x q0.y q0.z) max (q0.w q1.x q1.y)
+      float a1x = f_fma(q0.x, idir.x, nop.x), a2x = f_fma(q0.w, idir.x, nom.x);
+      float a1y = f_fma(q0.y, idir.y, nop.y), a2y = f_fma(q1.x, idir.y, nom.y);
+      float a1z = f_fma(q0.z, idir.z, nop.z), a2z = f_fma(q1.y, idir.z, nom.z);
+      float tn0 = f_max(f_max(f_min(a1x, a2x), f_min(a1y, a2y)), f_max(f_min(a1z, a2z), 0.0f));
+      float tf0 = f_min(f_min(f_max(a1x, a2x), f_max(a1y, a2y)), f_min(f_max(a1z, a2z), tb));
+      // child 1: min (q1.z q1.w q2.x) max (q2.y q2.z q2.w)
+      float b1x = f_fma(q1.z, idir.x, nop.x), b2x = f_fma(q2.y, idir.x, nom.x);
+      float b1y = f_fma(q1.w, idir.y, nop.y), b2y = f_fma(q2.z, idir.y, nom.y);
+      float b1z = f_fma(q2.x, idir.z, nop.z), b2z = f_fma(q2.w, idir.z, nom.z);
+      float tn1 = f_max(f_max(f_min(b1x, b2x), f_min(b1y, b2y)), f_max(f_min(b1z, b2z), 0.0f));
+      float tf1 = f_min(f_min(f_max(b1x, b2x), f_max(b1y, b2y)), f_min(f_max(b1z, b2z), tb));
+      bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
+      int32_t c0 = as_int(q3.x), c1 = as_int(q3.y);
+      if (h0 && h1) {
+        bool swap = tn1 < tn0;
+        stk[sp * 64] = swap ? c0 : c1;
+        sp++;
+        cur = swap ? c1 : c0;
+      } else if (h0) {
+        cur = c0;
+      } else if (h1) {
+        cur = c1;
+      } else {
+        if (sp == 0) break;
+        sp--;
+        cur = stk[sp * 64];
+      }
+    } else {
+      uint32_t code = ~(uint32_t)cur;
+      uint32_t first = code >> 3, cnt = (code & 7u) + 1u;
+      for (uint32_t k = 0; k < cnt; k++) {
+        if (COUNT) lc.tri_tests++;
+        const float4* tv = S.tri_verts + 3 * (size_t)(first + k);
+        float4 r0 = tv[0], r1 = tv[1], r2 = tv[2];
+        // Moller-Trumbore with back-face culling, RS:199-234 (edge1/edge2 pre-subtracted on upload)
+        v3 edge1 = xyz(r1), edge2 = xyz(r2);
+        v3 pvec = cross(d, edge2);
+        float det = dot(edge1, pvec);
+        if (det < kEPSILON) continue;
+        float inv_det = 1.0f / det;
+        v3 tvec = o - xyz(r0);
+        float u = dot(tvec, pvec) * inv_det;
+        if (u < 0.0f || u > 1.0f) continue;
+        v3 qvec = cross(tvec, edge1);
+        float v = dot(d, qvec) * inv_det;
+        if (v < 0.0f || u + v > 1.0f) continue;
+        float t = dot(edge2, qvec) * inv_det;
+        int islot = as_int(r0.w);
+        bool closer = (t > 0 && t < best.t) || (t > 0 && t == best.t && best_i >= 0 && islot < best_i);  // RS:251 + A.4
+        if (closer) { best.t = t; best.kind = 3; best.id = (int)(first + k); best.u = u; best.v = v; best_i = islot; }
+      }
+      if (sp == 0) break;
+      sp--;
+      cur = stk[sp * 64];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Trace — RS:364-383: ground plane, then the mesh object BVH, then the sphere BVH.
+// tl / bl: this lane's LDS stacks for the object-level and the triangle-level traversals.
+// ---------------------------------------------------------------------------------------------------
+template <bool COUNT>
+__device__ __forceinline__ HitRec trace(const DevScene& S, v3 o, v3 d, int* tl, int* bl, LocalCounters& lc) {
+  lc.rays++;
+  HitRec best; best.t = URT_INF; best.kind = 0; best.id = 0; best.u = 0; best.v = 0;
+  // IntersectGroundPlane RS:156-172
+  {
+    float t = -o.y / d.y;
+    if (t > 0 && t < best.t) { best.t = t; best.kind = 1; }
+  }
+  // one reciprocal per axis for the object-level slab test (normative form of RS:282-283)
+  v3 rcp = mk3(1.0f / (d.x + kEPSILON), 1.0f / (d.y + kEPSILON), 1.0f / (d.z + kEPSILON));
+  // IntersectMeshBVH RS:294-326 (`tests` is never reset: once a leaf was reached, every later popped
+  // node has its object intersected, A.5; object ids < 0 or out of range are skipped, not read)
+  if (S.n_meshes > 0) {
+    int check = 1; tl[0] = 0; bool seen = false;
+    while (check > 0) {
+      check--;
+      int bi = tl[check * 64];
+      bool hit = false; int index = -1;
+      if (bi < S.n_mesh_tlas) {
+        if (COUNT) lc.tlas_nodes++;
+        float4 a = S.mesh_tlas[2 * bi], b = S.mesh_tlas[2 * bi + 1];
+        index = as_int(a.w);
+        hit = tlas_slab(a, b, o, rcp);
+      }
+      if (hit) {
+        if (index < 0) { tl[check * 64] = bi * 2 + 1; check++; tl[check * 64] = bi * 2 + 2; check++; }
+        else seen = true;
+      }
+      if (seen && index >= 0 && index < S.n_meshes) intersect_mesh<COUNT>(S, S.mesh_root[index], o, d, best, bl, lc);
+    }
+  }
+  // IntersectSphereBVH RS:329-361
+  if (S.n_spheres > 0) {
+    int check = 1; tl[0] = 0; bool seen = false;
+    while (check > 0) {
+      check--;
+      int bi = tl[check * 64];
+      bool hit = false; int index = -1;
+      if (bi < S.n_sphere_tlas) {
+        if (COUNT) lc.tlas_nodes++;
+        float4 a = S.sphere_tlas[2 * bi], b = S.sphere_tlas[2 * bi + 1];
+        index = as_int(a.w);
+        hit = tlas_slab(a, b, o, rcp);
+      }
+      if (hit) {
+        if (index < 0) { tl[check * 64] = bi * 2 + 1; check++; tl[check * 64] = bi * 2 + 2; check++; }
+        else seen = true;
+      }
+      if (seen && index >= 0 && index < S.n_spheres) intersect_sphere<COUNT>(S, index, o, d, best, lc);
+    }
+  }
+  return best;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Shade — RS:386-428 (+ SampleHemisphere RS:103-111, GetTangentSpace RS:89-100, sky lookup A.11)
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ v3 sample_hemisphere(v3 normal, float alpha, float& seed, float px, float py) {
+  float cosTheta = f_pow(rand_next(seed, px, py), 1.0f / (alpha + 1.0f));
+  float sinTheta = f_sqrt(1.0f - cosTheta * cosTheta);
+  float phi = (2.0f * kPI) * rand_next(seed, px, py);
+  float sp, cp; f_sincos(phi, sp, cp);
+  v3 ts = mk3(cp * sinTheta, sp * sinTheta, cosTheta);
+  v3 helper = mk3(1, 0, 0);
+  if (f_abs(normal.x) > 0.99f) helper = mk3(0, 0, 1);
+  v3 tangent = normalize(cross(normal, helper));
+  v3 binormal = normalize(cross(normal, tangent));
+  return mk3(f_fma(ts.z, normal.x, f_fma(ts.y, binormal.x, ts.x * tangent.x)),
+             f_fma(ts.z, normal.y, f_fma(ts.y, binormal.y, ts.x * tangent.y)),
+             f_fma(ts.z, normal.z, f_fma(ts.y, binormal.z, ts.x * tangent.z)));
+}
+
+__device__ __forceinline__ v3 sample_sky(const DevScene& S, float u, float v) {
+  int W = S.sky_w, H = S.sky_h;
+  float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
+  float x0f = f_floor(x), y0f = f_floor(y);
+  float fx = x - x0f, fy = y - y0f;
+  int x0 = (int)x0f, y0 = (int)y0f;
+  x0 %= W; if (x0 < 0) x0 += W;
+  y0 %= H; if (y0 < 0) y0 += H;
+  int x1 = x0 + 1; if (x1 == W) x1 = 0;
+  int y1 = y0 + 1; if (y1 == H) y1 = 0;
+  float4 c00 = S.sky[(size_t)y0 * W + x0], c10 = S.sky[(size_t)y0 * W + x1];
+  float4 c01 = S.sky[(size_t)y1 * W + x0], c11 = S.sky[(size_t)y1 * W + x1];
+  float ax = f_fma(fx, c10.x - c00.x, c00.x), bx = f_fma(fx, c11.x - c01.x, c01.x);
+  float ay = f_fma(fx, c10.y - c00.y, c00.y), by = f_fma(fx, c11.y - c01.y, c01.y);
+  float az = f_fma(fx, c10.z - c00.z, c00.z), bz = f_fma(fx, c11.z - c01.z, c01.z);
+  return mk3(f_fma(fy, bx - ax, ax), f_fma(fy, by - ay, ay), f_fma(fy, bz - az, az));
+}
+
+// One bounce's shading: result += energy_before * Shade(ray, hit) (A.3); returns any(energy) (RS:457).
+template <bool COUNT>
+__device__ __forceinline__ bool shade(const DevScene& S, const HitRec& h, v3& o, v3& d, v3& energy, v3& result,
+                                      float& seed, float px, float py, LocalCounters& lc) {
+  v3 e0 = energy;
+  v3 s;
+  if (h.t < URT_INF) {
+    v3 pos = madd(h.t, d, o);
+    v3 n, albedo, spec, emission; float smooth;
+    if (h.kind == 1) {                       // RS:164-170
+      if (COUNT) lc.hit_ground++;
+      n = mk3(0, 1, 0);
+      albedo = mk3(0.5f, 0.3f, 0.15f); spec = mk3(0, 0, 0); emission = mk3(0, 0, 0); smooth = 0.3f;
+    } else {
+      const float4* m;
+      if (h.kind == 2) {                     // RS:192-194
+        if (COUNT) lc.hit_sphere++;
+        n = normalize(pos - xyz(S.sphere_pr[h.id]));
+        m = S.sphere_mat + 3 * (size_t)h.id;
+      } else {                               // RS:259-264
+        if (COUNT) lc.hit_tri++;
+        const float4* tn = S.tri_norms + 3 * (size_t)h.id;
+        v3 n0 = xyz(tn[0]), n1 = xyz(tn[1]), n2 = xyz(tn[2]);
+        float w = 1.0f - h.u - h.v;
+        n = normalize((n0 * w) + (n1 * h.u) + (n2 * h.v));
+        int mesh = as_int(S.tri_verts[3 * (size_t)h.id + 1].w);
+        m = S.mesh_mat + 3 * (size_t)mesh;
+      }
+      float4 m0 = m[0], m1 = m[1], m2 = m[2];
+      albedo = xyz(m0); smooth = m0.w; spec = xyz(m1); emission = xyz(m2);
+    }
+    albedo = vmin3(mk3(1.0f, 1.0f, 1.0f) - spec, albedo);
+    const float third = 1.0f / 3.0f;
+    float specChance = dot(spec, mk3(third, third, third));
+    float diffChance = dot(albedo, mk3(third, third, third));
+    float sum = specChance + diffChance;
+    specChance /= sum;
+    diffChance /= sum;
+    float roulette = rand_next(seed, px, py);
+    if (roulette < specChance) {
+      float alpha = f_pow(1000.0f, smooth * smooth);
+      o = madd(0.001f, n, pos);
+      d = sample_hemisphere(reflect(d, n), alpha, seed, px, py);
+      float f = (alpha + 2) / (alpha + 1);
+      float sd = f_saturate(dot(n, d) * f);
+      energy = energy * (((1.0f / specChance) * spec) * sd);
+    } else if (diffChance > 0 && roulette < specChance + diffChance) {
+      o = madd(0.001f, n, pos);
+      d = sample_hemisphere(n, 1.0f, seed, px, py);
+      energy = energy * ((1.0f / diffChance) * albedo);
+    } else {
+      energy = mk3(0, 0, 0);
+    }
+    s = emission;
+  } else {
+    if (COUNT) lc.hit_sky++;
+    energy = mk3(0, 0, 0);
+    float theta = f_acos(d.y) / -kPI;
+    float phi = f_atan2(d.x, -d.z) / -kPI * 0.5f;
+    s = sample_sky(S, phi, theta);
+  }
+  result = result + e0 * s;
+  return any_nonzero(energy);
+}
+
+// CreateCameraRay RS:142-153 with the uv of RS:448-449
+__device__ __forceinline__ void camera_ray(const FrameParams& P, int x, int y, float& seed, v3& o, v3& d) {
+  float px = (float)x, py = (float)y;
+  float r0 = rand_next(seed, px, py);
+  float r1 = rand_next(seed, px, py);
+  float u = (px + r0 + P.pixel_off_x) / (float)P.width * 2.0f - 1.0f;
+  float v = (py + r1 + P.pixel_off_y) / (float)P.height * 2.0f - 1.0f;
+  o = mul_m4(P.c2w, 0.0f, 0.0f, 0.0f, 1.0f);
+  v3 dir = mul_m4(P.invp, u, v, 0.0f, 1.0f);
+  dir = mul_m4(P.c2w, dir.x, dir.y, dir.z, 0.0f);
+  d = normalize(dir);
+}
+
+// tile -> pixel: one 8x8 tile per wave (the reference's [numthreads(8,8,1)] group, RS:431).
+// Blocks are dealt round-robin to the 8 XCDs (b % 8 shares an XCD): give each XCD a contiguous
+// band of tiles so that its private L2 serves one part of the scene.
+__device__ __forceinline__ bool tile_pixel(const FrameParams& P, int& x, int& y) {
+  int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int nblocks = gridDim.x;
+  int b = blockIdx.x;
+  int per_xcd = (nblocks + 7) >> 3;
+  int sb = (b & 7) * per_xcd + (b >> 3);          // swizzled block id in [0, 8*per_xcd)
+  int tile = sb * (blockDim.x >> 6) + wave;
+  int ntiles = P.tiles_x * P.n_strips;
+  if (tile >= ntiles) return false;
+  int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
+  x = tx * 8 + (lane & 7);
+  y = (P.first_group_row + ty * P.row_stride) * 8 + (lane >> 3);
+  return x < P.region_w && y < P.region_h;
+}
+
+__device__ __forceinline__ unsigned int wave_sum(unsigned int v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+template <bool COUNT>
+__device__ __forceinline__ void flush_counters(const LocalCounters& lc, DevCounters* ctr) {
+  // wave-reduce then one atomic per wave and counter (diagnostic path; `rays`/`pixels` always)
+  unsigned int r = wave_sum(lc.rays), p = wave_sum(lc.pixels);
+  unsigned int tn = 0, bn = 0, tt = 0, st = 0, ht = 0, hs = 0, hg = 0, hk = 0;
+  if (COUNT) {
+    tn = wave_sum(lc.tlas_nodes); bn = wave_sum(lc.blas_nodes); tt = wave_sum(lc.tri_tests); st = wave_sum(lc.sphere_tests);
+    ht = wave_sum(lc.hit_tri); hs = wave_sum(lc.hit_sphere); hg = wave_sum(lc.hit_ground); hk = wave_sum(lc.hit_sky);
+  }
+  if ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) {
+    if (r) atomicAdd(&ctr->rays, (unsigned long long)r);
+    if (p) atomicAdd(&ctr->pixels, (unsigned long long)p);
+    if (COUNT) {
+      if (tn) atomicAdd(&ctr->tlas_nodes, (unsigned long long)tn);
+      if (bn) atomicAdd(&ctr->blas_nodes, (unsigned long long)bn);
+      if (tt) atomicAdd(&ctr->tri_tests, (unsigned long long)tt);
+      if (st) atomicAdd(&ctr->sphere_tests, (unsigned long long)st);
+      if (ht) atomicAdd(&ctr->hit_tri, (unsigned long long)ht);
+      if (hs) atomicAdd(&ctr->hit_sphere, (unsigned long long)hs);
+      if (hg) atomicAdd(&ctr->hit_ground, (unsigned long long)hg);
+      if (hk) atomicAdd(&ctr->hit_sky, (unsigned long long)hk);
+    }
+  }
+}
+
+__device__ __forceinline__ void lane_stacks(const FrameParams& P, int*& tl, int*& bl) {
+  extern __shared__ int lds[];
+  int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int per_wave = (P.tlas_stack + P.blas_stack) * 64;
+  tl = lds + wave * per_wave + lane;
+  bl = tl + P.tlas_stack * 64;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// mode 0: per-pixel megakernel — the whole of CSMain (RS:431-469) in one thread.
+// ---------------------------------------------------------------------------------------------------
+template <bool COUNT>
+__global__ __launch_bounds__(256) void k_mega(DevScene S, FrameParams P, float4* __restrict__ result, DevCounters* ctr) {
+  int *tl, *bl;
+  lane_stacks(P, tl, bl);
+  LocalCounters lc;
+  int x, y;
+  if (tile_pixel(P, x, y)) {
+    float px = (float)x, py = (float)y;
+    float seed = P.seed;
+    v3 avg = mk3(0, 0, 0);
+    for (int i = 0; i < P.num_rays; i++) {
+      v3 res = mk3(0, 0, 0);
+      v3 o, d, energy = mk3(1, 1, 1);
+      camera_ray(P, x, y, seed, o, d);
+      for (int k = 0; k < P.num_bounces; k++) {
+        HitRec h = trace<COUNT>(S, o, d, tl, bl, lc);
+        if (!shade<COUNT>(S, h, o, d, energy, res, seed, px, py, lc)) break;
+      }
+      avg = avg + res;
+    }
+    float n = (float)P.num_rays;
+    result[(size_t)y * P.width + x] = make_float4(avg.x / n, avg.y / n, avg.z / n, 1.0f);
+    lc.pixels++;
+  }
+  flush_counters<COUNT>(lc, ctr);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// mode 1: wavefront pipeline.  generate -> (bounce x num_bounces) per ray index, over compacted queues.
+// ---------------------------------------------------------------------------------------------------
+// Append the alive lanes of this wave to a queue: ballot, prefix popcount, one atomic per wave.
+__device__ __forceinline__ int wave_append(bool alive, unsigned int* counter) {
+  unsigned long long m = __ballot(alive);
+  if (m == 0) return -1;
+  int lane = threadIdx.x & 63;
+  int leader = __ffsll((long long)m) - 1;
+  unsigned int base = 0;
+  if (lane == leader) base = atomicAdd(counter, (unsigned int)__popcll(m));
+  base = __shfl(base, leader, 64);
+  int rank = __popcll(m & ((1ull << lane) - 1ull));
+  return alive ? (int)(base + rank) : -1;
+}
+
+// Path finished: fold its radiance into the pixel.  Result.xyz holds the running resultAverage
+// (RS:441,464) and .w the running _Seed between the rays of one pixel; the last ray writes RS:468.
+__device__ __forceinline__ void finish_path(const FrameParams& P, float4* result, int pixel, int ray_index, v3 res, float seed) {
+  int x = pixel & 0xffff, y = (unsigned)pixel >> 16;
+  size_t at = (size_t)y * P.width + x;
+  v3 avg = res;
+  if (ray_index > 0) { float4 prev = result[at]; avg = xyz(prev) + res; }
+  if (ray_index == P.num_rays - 1) {
+    float n = (float)P.num_rays;
+    result[at] = make_float4(avg.x / n, avg.y / n, avg.z / n, 1.0f);
+  } else {
+    result[at] = make_float4(avg.x, avg.y, avg.z, seed);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_generate(FrameParams P, PathQueues Q, const float4* __restrict__ result,
+                                                  int ray_index, DevCounters* ctr) {
+  int x = 0, y = 0;
+  bool ok = tile_pixel(P, x, y);
+  float seed = P.seed;
+  v3 o = mk3(0, 0, 0), d = mk3(0, 0, 0);
+  if (ok) {
+    if (ray_index > 0) seed = result[(size_t)y * P.width + x].w;
+    camera_ray(P, x, y, seed, o, d);
+  }
+  unsigned int* cnt = Q.counts + (size_t)ray_index * (P.num_bounces + 1);
+  int slot = wave_append(ok, cnt);
+  if (ok) {
+    Q.s[0][0][slot] = make_float4(o.x, o.y, o.z, seed);
+    Q.s[0][1][slot] = make_float4(d.x, d.y, d.z, as_float((y << 16) | x));
+    Q.s[0][2][slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+    Q.s[0][3][slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  }
+  if (ray_index == 0) {
+    unsigned int p = wave_sum(ok ? 1u : 0u);
+    if ((threadIdx.x & 63) == 0 && p) atomicAdd(&ctr->pixels, (unsigned long long)p);
+  }
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(256) void k_bounce(DevScene S, FrameParams P, PathQueues Q, float4* __restrict__ result,
+                                                int ray_index, int bounce, DevCounters* ctr) {
+  int *tl, *bl;
+  lane_stacks(P, tl, bl);
+  LocalCounters lc;
+  unsigned int* cnt = Q.counts + (size_t)ray_index * (P.num_bounces + 1) + bounce;
+  unsigned int n_in = cnt[0];
+  unsigned int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  int in = bounce & 1, out = in ^ 1;
+  bool alive = false;
+  v3 o, d, energy, res; float seed = 0; int pixel = 0;
+  if (gid < n_in) {
+    float4 s0 = Q.s[in][0][gid], s1 = Q.s[in][1][gid], s2 = Q.s[in][2][gid], s3 = Q.s[in][3][gid];
+    o = xyz(s0); seed = s0.w; d = xyz(s1); pixel = as_int(s1.w); energy = xyz(s2); res = xyz(s3);
+    float px = (float)(pixel & 0xffff), py = (float)((unsigned)pixel >> 16);
+    HitRec h = trace<COUNT>(S, o, d, tl, bl, lc);
+    alive = shade<COUNT>(S, h, o, d, energy, res, seed, px, py, lc);
+    if (bounce == P.num_bounces - 1) alive = false;      // loop bound RS:453
+    if (!alive) finish_path(P, result, pixel, ray_index, res, seed);
+  }
+  int slot = wave_append(alive, cnt + 1);
+  if (alive) {
+    Q.s[out][0][slot] = make_float4(o.x, o.y, o.z, seed);
+    Q.s[out][1][slot] = make_float4(d.x, d.y, d.z, as_float(pixel));
+    Q.s[out][2][slot] = make_float4(energy.x, energy.y, energy.z, 0.0f);
+    Q.s[out][3][slot] = make_float4(res.x, res.y, res.z, 0.0f);
+  }
+  flush_counters<COUNT>(lc, ctr);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// AdditionShader — AS:9,39-41 as driven by RM:817-818.  dst = src*a + dst*(1-a), a = 1/(sample+1);
+// the fragment's alpha is a itself.  16 B per lane, grid-stride.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_blit_add(const float4* __restrict__ src, float4* __restrict__ dst, size_t n, float sample) {
+  float a = 1.0f / (sample + 1.0f);
+  float ia = 1.0f - a;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float4 t = src[i], c = dst[i];
+    c.x = t.x * a + c.x * ia;
+    c.y = t.y * a + c.y * ia;
+    c.z = t.z * a + c.z * ia;
+    c.w = a * a + c.w * ia;
+    dst[i] = c;
+  }
+}
+
+// strips <-> dense buffer (frame-end gather): strip j of this rank = pixel rows (first + j*stride)*8 .. +8
+__global__ __launch_bounds__(256) void k_pack_rows(const float4* __restrict__ img, float4* __restrict__ dense, int width, int height,
+                                                   int first_group_row, int row_stride, int n_strips, int to_dense) {
+  size_t per_strip = (size_t)width * 8;
+  size_t n = per_strip * (size_t)n_strips;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    int j = (int)(i / per_strip);
+    size_t r = i - (size_t)j * per_strip;
+    int row = (first_group_row + j * row_stride) * 8 + (int)(r / (size_t)width);
+    int col = (int)(r % (size_t)width);
+    if (row < height) {
+      size_t at = (size_t)row * width + col;
+      if (to_dense) dense[i] = img[at]; else const_cast<float4*>(img)[at] = dense[i];
+    } else if (to_dense) {
+      dense[i] = make_float4(0, 0, 0, 0);
+    }
+  }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------
+// host-side launchers (declared in kernels.h)
+// ---------------------------------------------------------------------------------------------------
+namespace urtd {
+
+static inline int blocks_for_tiles(const FrameParams& P) {
+  int ntiles = P.tiles_x * P.n_strips;
+  int nblocks = (ntiles + 3) / 4;
+  return ((nblocks + 7) / 8) * 8;   // multiple of 8 so the XCD swizzle is a bijection onto [0, nblocks)
+}
+
+hipError_t launch_mega(const DevScene& S, const FrameParams& P, float4* result, DevCounters* ctr, bool count, hipStream_t st) {
+  int nb = blocks_for_tiles(P);
+  if (nb == 0) return hipSuccess;
+  size_t lds = (size_t)(P.tlas_stack + P.blas_stack) * 64 * 4 * sizeof(int);
+  if (count) hipLaunchKernelGGL(k_mega<true>, dim3(nb), dim3(256), lds, st, S, P, result, ctr);
+  else hipLaunchKernelGGL(k_mega<false>, dim3(nb), dim3(256), lds, st, S, P, result, ctr);
+  return hipGetLastError();
+}
+
+hipError_t launch_wavefront(const DevScene& S, const FrameParams& P, const PathQueues& Q, float4* result, DevCounters* ctr,
+                            bool count, hipStream_t st) {
+  int nb = blocks_for_tiles(P);
+  if (nb == 0) return hipSuccess;
+  size_t lds = (size_t)(P.tlas_stack + P.blas_stack) * 64 * 4 * sizeof(int);
+  size_t n_counts = (size_t)P.num_rays * (P.num_bounces + 1);
+  hipError_t e = hipMemsetAsync(Q.counts, 0, n_counts * sizeof(unsigned int), st);
+  if (e != hipSuccess) return e;
+  size_t npix = (size_t)P.region_w * 8 * P.n_strips;
+  int nbb = (int)((npix + 255) / 256);
+  for (int i = 0; i < P.num_rays; i++) {
+    hipLaunchKernelGGL(k_generate, dim3(nb), dim3(256), 0, st, P, Q, (const float4*)result, i, ctr);
+    for (int k = 0; k < P.num_bounces; k++) {
+      if (count) hipLaunchKernelGGL(k_bounce<true>, dim3(nbb), dim3(256), lds, st, S, P, Q, result, i, k, ctr);
+      else hipLaunchKernelGGL(k_bounce<false>, dim3(nbb), dim3(256), lds, st, S, P, Q, result, i, k, ctr);
+    }
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_blit_add(const float4* src, float4* dst, size_t n_pixels, float sample, hipStream_t st) {
+  if (n_pixels == 0) return hipSuccess;
+  size_t nb = (n_pixels + 255) / 256;
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(k_blit_add, dim3((unsigned)nb), dim3(256), 0, st, src, dst, n_pixels, sample);
+  return hipGetLastError();
+}
+
+hipError_t launch_pack_rows(float4* img, float4* dense, int width, int height, int first_group_row, int row_stride,
+                            int n_strips, bool to_dense, hipStream_t st) {
+  size_t n = (size_t)width * 8 * (size_t)n_strips;
+  if (n == 0) return hipSuccess;
+  size_t nb = (n + 255) / 256;
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)nb), dim3(256), 0, st, (const float4*)img, dense, width, height,
+                     first_group_row, row_stride, n_strips, to_dense ? 1 : 0);
+  return hipGetLastError();
+}
+
+}  // namespace urtd

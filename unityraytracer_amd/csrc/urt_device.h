@@ -1,0 +1,67 @@
+// urt_device.h — device-side scene/frame descriptors shared by the host library (context.cpp) and the
+// HIP kernels (kernels.hip).  Layouts are the library's own (SoA / 16-byte records for coalesced
+// dwordx4 loads); they are derived on upload from the reference layouts of urt_types.h.
+#pragma once
+#include <stdint.h>
+#include <hip/hip_runtime.h>
+
+#include "blas_builder.h"   // kBlasNodeFloats, kEmptyMeshRoot
+
+namespace urtd {
+
+// Triangle BVH ("BLAS") node: 64 bytes = 4 x float4
+//   q0 = c0.min.xyz, c0.max.x     q1 = c0.max.yz, c1.min.xy
+//   q2 = c1.min.z, c1.max.xyz     q3 = child0, child1 (int bits), 0, 0
+// child >= 0: interior node index.  child < 0: leaf, code = ~child, first leaf-order triangle slot =
+// code >> 3, count = (code & 7) + 1.  Host-side/introspection layout is the flat 16-float form
+// [c0.min c0.max c1.min c1.max child0 child1 0 0]; it is the same bytes.
+struct DevScene {
+  // object-level BVHs in the reference's implicit-heap order (RS:57-61,70-71), repacked to 32 B:
+  //   [2i] = vmin.xyz, index (int bits)    [2i+1] = vmax.xyz, 0
+  const float4* mesh_tlas;   int n_mesh_tlas;
+  const float4* sphere_tlas; int n_sphere_tlas;
+  // spheres (RS:51-55): position.xyz + radius; materials as 3 x float4
+  const float4* sphere_pr;   int n_spheres;
+  const float4* sphere_mat;  // [3i] albedo.xyz, smoothness  [3i+1] specular.xyz, 0  [3i+2] emission.xyz, 0
+  // mesh objects (RS:43-49)
+  const int32_t* mesh_root;  int n_meshes;
+  const float4* mesh_mat;    // same 3 x float4 form
+  // triangle BVH over world-space triangles, all meshes in one pool
+  const float4* blas_nodes;  // 4 x float4 per node
+  const float4* tri_verts;   // [3k] v0.xyz, index slot i (int bits)  [3k+1] e1.xyz, mesh id (int bits)  [3k+2] e2.xyz, 0
+  const float4* tri_norms;   // [3k..3k+2] n0, n1, n2 (object space, RS:259-261)
+  // sky (RS:9-10): RGBA32F, row 0 = bottom, bilinear + repeat
+  const float4* sky;         int sky_w, sky_h;
+};
+
+struct FrameParams {
+  float c2w[16];            // _CameraToWorld            RS:5
+  float invp[16];           // _CameraInverseProjection  RS:6
+  float pixel_off_x, pixel_off_y;   // _PixelOffset      RS:7
+  float seed;               // _Seed                     RS:16
+  int num_bounces;          // _numBounces               RS:18
+  int num_rays;             // _numRays                  RS:19
+  int width, height;        // Result.GetDimensions      RS:438
+  int region_w, region_h;   // min(8*groupsX, W), min(8*groupsY, H): pixels the dispatch covers
+  int tiles_x;              // ceil(region_w / 8)
+  int first_group_row;      // multi-GPU strips: global group row of local strip 0
+  int row_stride;           //                   and the stride between this rank's strips
+  int n_strips;             // local strips (8 pixel rows each)
+  int tlas_stack;           // LDS entries per lane reserved for the object-level stacks
+  int blas_stack;           // LDS entries per lane reserved for the triangle-BVH stack
+};
+
+struct DevCounters {       // 64-bit device counters, accumulated with atomics
+  unsigned long long rays, tlas_nodes, blas_nodes, tri_tests, sphere_tests;
+  unsigned long long hit_tri, hit_sphere, hit_ground, hit_sky, pixels;
+};
+
+// path state of the wavefront pipeline: 4 x float4 per path, SoA by record
+//   s0 = origin.xyz, seed   s1 = direction.xyz, pixel (int bits: y << 16 | x)
+//   s2 = energy.xyz, 0      s3 = result.xyz, 0
+struct PathQueues {
+  float4* s[2][4];          // ping-pong
+  unsigned int* counts;     // [num_rays * (num_bounces + 1)] live-path counts per (ray, bounce)
+};
+
+}  // namespace urtd

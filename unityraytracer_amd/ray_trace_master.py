@@ -1,0 +1,178 @@
+"""Host-side mirror of Assets/Scripts/RayTraceMaster.cs — the frame driver around the hot path.
+
+Method names and order of GPU calls follow the reference (RM = RayTraceMaster.cs):
+
+    OnRenderImage (RM:848-866)  ->  [RebuildTrees (RM:725-746)]  ->  SetShaderParameters (RM:772-795)
+                                ->  Render (RM:798-821)  ->  InitRenderTexture (RM:824-845)
+
+The scene arrives already flattened (a `scenes.Scene`: what RebuildObjectLists RM:262-336 and the BVH
+builder RM:405-722 produce); `RebuildTrees` here is the upload half of the reference's: the seven
+CreateComputeBuffer calls (RM:738-745).  `UnityEngine.Random.value` (RM:777-778) is replaced by the
+documented splitmix64 frame sequence of scenes.frame_uniforms so that frames are reproducible.
+
+Multi-GPU (one process per GPU): construct with rank/world_size; each rank renders the 8-row strips
+rank, rank+world, ... with GLOBAL pixel ids and accumulates locally; `gather_converged` moves the
+strips to rank 0 with one collective at frame end.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from . import scenes
+from .unity_api import ComputeBuffer, ComputeShader, Context, Graphics, Material, RenderTexture
+
+
+class RayTraceMaster:
+    MeshObjectStructSize = 112   # RM:43
+    SphereStructSize = 56        # RM:44
+    BVHNodeSize = 28             # RM:45
+
+    def __init__(self, ctx: Context, scene: scenes.Scene, rank: int = 0, world_size: int = 1, frame_seed: int = 0x5EED):
+        self.ctx = ctx
+        self.RayTraceShader = ComputeShader(ctx)
+        self.scene = scene
+        self.numBounces = scene.num_bounces          # RM:17
+        self.numRays = scene.num_rays                # RM:18
+        self.rank, self.world_size = rank, world_size
+        self.frame_seed = frame_seed
+        self._currentSample = 0                      # RM:19
+        self._frame = 0
+        self._target = None                          # RM:11
+        self._converged = None                       # RM:12
+        self._additionMaterial = None                # RM:20
+        self._treesNeedRebuilding = True             # RM:24
+        self.SkyboxTexture = None                    # RM:10
+        self._meshObjectBuffer = self._vertexBuffer = self._indexBuffer = self._normalBuffer = None
+        self._sphereBuffer = self._meshObjectBVHBuffer = self._sphereBVHBuffer = None
+        self.screen_width, self.screen_height = scene.width, scene.height
+
+    # RM:233-252
+    def CreateComputeBuffer(self, buffer, data: np.ndarray, stride: int):
+        count = data.nbytes // stride
+        if buffer is not None and (count == 0 or buffer.count != count or buffer.stride != stride):
+            buffer.Release()
+            buffer = None
+        if count != 0:
+            if buffer is None:
+                buffer = ComputeBuffer(self.ctx, count, stride)
+            buffer.SetData(data)
+        return buffer
+
+    # RM:255-259
+    def SetComputeBuffer(self, name: str, buffer):
+        if buffer is not None:
+            self.RayTraceShader.SetBuffer(0, name, buffer)
+
+    # RM:725-746 (upload half)
+    def RebuildTrees(self):
+        s = self.scene
+        self._meshObjectBuffer = self.CreateComputeBuffer(self._meshObjectBuffer, s.mesh_objects, self.MeshObjectStructSize)
+        self._vertexBuffer = self.CreateComputeBuffer(self._vertexBuffer, np.ascontiguousarray(s.vertices, np.float32), 12)
+        self._indexBuffer = self.CreateComputeBuffer(self._indexBuffer, np.ascontiguousarray(s.indices, np.int32), 4)
+        self._normalBuffer = self.CreateComputeBuffer(self._normalBuffer, np.ascontiguousarray(s.normals, np.float32), 12)
+        self._sphereBuffer = self.CreateComputeBuffer(self._sphereBuffer, s.spheres, self.SphereStructSize)
+        self._meshObjectBVHBuffer = self.CreateComputeBuffer(self._meshObjectBVHBuffer, s.mesh_bvh, self.BVHNodeSize)
+        self._sphereBVHBuffer = self.CreateComputeBuffer(self._sphereBVHBuffer, s.sphere_bvh, self.BVHNodeSize)
+        if self.SkyboxTexture is None and s.sky is not None:
+            h, w = s.sky.shape[:2]
+            self.SkyboxTexture = RenderTexture(self.ctx, w, h)
+            self.SkyboxTexture.SetPixels(s.sky)
+
+    # RM:772-795
+    def SetShaderParameters(self):
+        sh, s = self.RayTraceShader, self.scene
+        sh.SetMatrix("_CameraToWorld", s.camera_to_world)
+        sh.SetMatrix("_CameraInverseProjection", s.camera_inverse_projection)
+        sh.SetTexture(0, "_SkyboxTexture", self.SkyboxTexture)
+        ox, oy, seed = scenes.frame_uniforms(self._frame, self.frame_seed) if self._frame else (s.pixel_offset[0], s.pixel_offset[1], s.seed)
+        sh.SetVector("_PixelOffset", (ox, oy))
+        sh.SetFloat("_Seed", seed)
+        sh.SetInt("_numBounces", self.numBounces)
+        sh.SetInt("_numRays", self.numRays)
+        sh.SetInt("_MeshBVH_len", len(s.mesh_bvh))
+        sh.SetInt("_SphereBVH_len", len(s.sphere_bvh))
+        self.SetComputeBuffer("_MeshObjects", self._meshObjectBuffer)
+        self.SetComputeBuffer("_Vertices", self._vertexBuffer)
+        self.SetComputeBuffer("_Indices", self._indexBuffer)
+        self.SetComputeBuffer("_Normals", self._normalBuffer)
+        self.SetComputeBuffer("_Spheres", self._sphereBuffer)
+        self.SetComputeBuffer("_MeshBVH", self._meshObjectBVHBuffer)
+        self.SetComputeBuffer("_SphereBVH", self._sphereBVHBuffer)
+
+    # RM:824-845
+    def InitRenderTexture(self):
+        if self._target is None or self._target.width != self.screen_width or self._target.height != self.screen_height:
+            if self._target is not None:
+                self._target.Release()
+                self._converged.Release()
+            self._target = RenderTexture(self.ctx, self.screen_width, self.screen_height)
+            self._converged = RenderTexture(self.ctx, self.screen_width, self.screen_height)
+            self._currentSample = 0
+
+    # RM:798-821
+    def Render(self, destination: RenderTexture | None = None):
+        self.InitRenderTexture()
+        self.RayTraceShader.SetTexture(0, "Result", self._target)
+        threadGroupsX = math.ceil(self.screen_width / 8.0)
+        threadGroupsY = math.ceil(self.screen_height / 8.0)
+        if self.world_size == 1:
+            self.RayTraceShader.Dispatch(0, threadGroupsX, threadGroupsY, 1)
+        else:
+            self.RayTraceShader.DispatchRows(0, threadGroupsX, threadGroupsY, 1, self.rank, self.world_size)
+        if self._additionMaterial is None:
+            self._additionMaterial = Material("Hidden/AdditionShader")
+        self._additionMaterial.SetFloat("_Sample", self._currentSample)
+        Graphics.Blit(self._target, self._converged, self._additionMaterial)
+        if destination is not None:
+            Graphics.Blit(self._converged, destination)
+        self._currentSample += 1
+        self._frame += 1
+
+    # RM:848-866
+    def OnRenderImage(self, destination: RenderTexture | None = None):
+        if self._treesNeedRebuilding:
+            self._currentSample = 0
+            self._treesNeedRebuilding = False
+            self.RebuildTrees()
+        self.SetShaderParameters()
+        self.Render(destination)
+
+    # RM:760-769: a camera move resets the running mean
+    def ResetAccumulation(self):
+        self._currentSample = 0
+
+    # RM:188-212
+    def OnDisable(self):
+        for b in (self._sphereBuffer, self._meshObjectBuffer, self._vertexBuffer, self._indexBuffer, self._normalBuffer,
+                  self._sphereBVHBuffer, self._meshObjectBVHBuffer):
+            if b is not None:
+                b.Release()
+        for t in (self._target, self._converged, self.SkyboxTexture):
+            if t is not None:
+                t.Release()
+        self._target = self._converged = self.SkyboxTexture = None
+
+    # ---- multi-GPU frame-end gather (no counterpart in the reference: it is single-GPU) -----------
+    def gather_converged(self, dist, device):
+        """One collective at frame end: every rank packs its strips of `_converged` into a dense device
+        buffer (k_pack_rows), rank 0 gathers (RCCL) and de-interleaves (k_pack_rows, reverse).
+        Returns the full image on rank 0 (numpy), else None."""
+        import torch
+        from . import strips
+        n_floats = strips.packed_rows(self.screen_height, self.world_size) * self.screen_width * 4
+        mine = torch.zeros(n_floats, dtype=torch.float32, device=device)
+        self._converged.pack_rows(self.rank, self.world_size, mine.data_ptr())
+        self.ctx.synchronize()
+        parts = strips.gather_to_root(dist, mine, self.rank, self.world_size)
+        if mine.is_cuda:
+            torch.cuda.synchronize(device)
+        if self.rank != 0:
+            return None
+        full = RenderTexture(self.ctx, self.screen_width, self.screen_height)
+        for r, p in enumerate(parts):
+            full.unpack_rows(r, self.world_size, p.data_ptr())
+        out = full.GetPixels()
+        full.Release()
+        return out

@@ -1,0 +1,222 @@
+"""Host-side mirror of the UnityEngine objects RayTraceMaster.cs drives, over the C ABI (include/urt.h).
+
+Same names, argument meaning and failure behaviour as the calls at RayTraceMaster.cs:233-259,
+772-845 so that code (and tests) written against the reference's host side read the same here:
+
+    ComputeBuffer(count, stride).SetData(list) / .Release() / .count / .stride        RM:233-252
+    ComputeShader.SetMatrix/SetVector/SetFloat/SetInt/SetTexture/SetBuffer/Dispatch   RM:772-810
+    RenderTexture(w, h) / .Release() / .width / .height                               RM:824-845
+    Material("Hidden/AdditionShader").SetFloat("_Sample", n); Graphics.Blit(...)      RM:813-819
+
+Unity's methods return void and log errors; here a failed call raises UrtError (carrying the C
+status and message) — a caller wanting Unity's behaviour catches, logs and continues.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import Counters, UrtError
+
+
+class Context:
+    """One per process and GPU (one-process-per-GPU model).  Owns the HIP stream all work is issued on."""
+
+    def __init__(self, device: int = 0):
+        self.lib = _lib.load()
+        self._h = C.c_void_p()
+        rc = self.lib.urt_context_create(int(device), C.byref(self._h))
+        if rc != 0:
+            raise UrtError(rc, self.lib.urt_last_error(None).decode())
+        self.device = device
+
+    def check(self, rc: int):
+        if rc != 0:
+            raise UrtError(rc, self.lib.urt_last_error(self._h).decode())
+
+    def close(self):
+        if self._h:
+            self.lib.urt_context_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def synchronize(self):
+        self.check(self.lib.urt_synchronize(self._h))
+
+    def set_stream(self, hip_stream: int | None):
+        self.check(self.lib.urt_context_set_stream(self._h, C.c_void_p(hip_stream or 0)))
+
+    def set_option(self, name: str, value: int):
+        self.check(self.lib.urt_set_option(self._h, name.encode(), int(value)))
+
+    def counters(self) -> dict:
+        c = Counters()
+        self.check(self.lib.urt_get_counters(self._h, C.byref(c)))
+        return c.as_dict()
+
+    def reset_counters(self):
+        self.check(self.lib.urt_reset_counters(self._h))
+
+
+class ComputeBuffer:
+    """UnityEngine.ComputeBuffer (RM:247-250)."""
+
+    def __init__(self, ctx: Context, count: int, stride: int):
+        self.ctx = ctx
+        h = C.c_uint64()
+        ctx.check(ctx.lib.urt_buffer_create(ctx._h, int(count), int(stride), C.byref(h)))
+        self.handle = h.value
+        self.count, self.stride = int(count), int(stride)
+
+    def SetData(self, data):
+        a = np.ascontiguousarray(data)
+        if a.nbytes % self.stride:
+            raise UrtError(1, f"SetData: {a.nbytes} bytes is not a multiple of stride {self.stride}")
+        self.ctx.check(self.ctx.lib.urt_buffer_set_data(self.ctx._h, self.handle, a.ctypes.data_as(C.c_void_p), a.nbytes // self.stride))
+
+    def Release(self):
+        if self.handle:
+            self.ctx.check(self.ctx.lib.urt_buffer_release(self.ctx._h, self.handle))
+            self.handle = 0
+
+
+class RenderTexture:
+    """UnityEngine.RenderTexture(w, h, 0, ARGBFloat, Linear) with enableRandomWrite (RM:834-840).
+    Row 0 is the bottom row.  `external_ptr` wraps caller-owned device memory (e.g. a torch tensor)."""
+
+    def __init__(self, ctx: Context, width: int, height: int, external_ptr: int | None = None):
+        self.ctx = ctx
+        h = C.c_uint64()
+        if external_ptr is None:
+            ctx.check(ctx.lib.urt_texture_create(ctx._h, int(width), int(height), C.byref(h)))
+        else:
+            ctx.check(ctx.lib.urt_texture_create_external(ctx._h, int(width), int(height), C.c_void_p(external_ptr), C.byref(h)))
+        self.handle = h.value
+        self.width, self.height = int(width), int(height)
+
+    def Release(self):
+        if self.handle:
+            self.ctx.check(self.ctx.lib.urt_texture_release(self.ctx._h, self.handle))
+            self.handle = 0
+
+    def SetPixels(self, rgba):
+        a = np.ascontiguousarray(rgba, dtype=np.float32)
+        if a.size != self.width * self.height * 4:
+            raise UrtError(1, "SetPixels: expected height*width*4 floats")
+        self.ctx.check(self.ctx.lib.urt_texture_set_pixels(self.ctx._h, self.handle, a.ctypes.data_as(C.c_void_p)))
+
+    def GetPixels(self) -> np.ndarray:
+        out = np.empty((self.height, self.width, 4), dtype=np.float32)
+        self.ctx.check(self.ctx.lib.urt_texture_get_pixels(self.ctx._h, self.handle, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def device_ptr(self) -> int:
+        p = C.c_void_p()
+        self.ctx.check(self.ctx.lib.urt_texture_get_info(self.ctx._h, self.handle, None, None, C.byref(p)))
+        return p.value
+
+    def packed_bytes(self, first_group_row: int, row_stride: int) -> int:
+        n = C.c_uint64()
+        self.ctx.check(self.ctx.lib.urt_texture_pack_rows(self.ctx._h, self.handle, first_group_row, row_stride, None, C.byref(n)))
+        return n.value
+
+    def pack_rows(self, first_group_row: int, row_stride: int, device_dst: int):
+        self.ctx.check(self.ctx.lib.urt_texture_pack_rows(self.ctx._h, self.handle, first_group_row, row_stride, C.c_void_p(device_dst), None))
+
+    def unpack_rows(self, first_group_row: int, row_stride: int, device_src: int):
+        self.ctx.check(self.ctx.lib.urt_texture_unpack_rows(self.ctx._h, self.handle, first_group_row, row_stride, C.c_void_p(device_src)))
+
+
+Texture2D = RenderTexture   # the sky is an ordinary RGBA32F image here
+
+
+class ComputeShader:
+    """UnityEngine.ComputeShader for RayTraceShader.compute; kernel 0 is CSMain."""
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+
+    def FindKernel(self, name: str) -> int:
+        if name != "CSMain":
+            raise UrtError(1, f"FindKernel: no kernel named {name}")
+        return 0
+
+    def SetMatrix(self, name: str, m16):
+        a = np.ascontiguousarray(m16, dtype=np.float32).reshape(16)
+        self.ctx.check(self.ctx.lib.urt_shader_set_matrix(self.ctx._h, name.encode(), a.ctypes.data_as(C.c_void_p)))
+
+    def SetVector(self, name: str, v):
+        a = np.zeros(4, dtype=np.float32)
+        v = np.asarray(v, dtype=np.float32).reshape(-1)
+        a[: len(v)] = v
+        self.ctx.check(self.ctx.lib.urt_shader_set_vector(self.ctx._h, name.encode(), a.ctypes.data_as(C.c_void_p)))
+
+    def SetFloat(self, name: str, v: float):
+        self.ctx.check(self.ctx.lib.urt_shader_set_float(self.ctx._h, name.encode(), float(v)))
+
+    def SetInt(self, name: str, v: int):
+        self.ctx.check(self.ctx.lib.urt_shader_set_int(self.ctx._h, name.encode(), int(v)))
+
+    def SetTexture(self, kernel: int, name: str, tex: RenderTexture | None):
+        self.ctx.check(self.ctx.lib.urt_shader_set_texture(self.ctx._h, kernel, name.encode(), tex.handle if tex else 0))
+
+    def SetBuffer(self, kernel: int, name: str, buf: ComputeBuffer | None):
+        self.ctx.check(self.ctx.lib.urt_shader_set_buffer(self.ctx._h, kernel, name.encode(), buf.handle if buf else 0))
+
+    def Dispatch(self, kernel: int, groups_x: int, groups_y: int, groups_z: int):
+        self.ctx.check(self.ctx.lib.urt_shader_dispatch(self.ctx._h, kernel, groups_x, groups_y, groups_z))
+
+    def DispatchRows(self, kernel: int, groups_x: int, groups_y: int, groups_z: int, first_group_row: int, row_stride: int):
+        """Multi-GPU extension: only the 8-row strips first_group_row, +row_stride, ... (global pixel ids kept)."""
+        self.ctx.check(self.ctx.lib.urt_shader_dispatch_rows(self.ctx._h, kernel, groups_x, groups_y, groups_z, first_group_row, row_stride))
+
+
+class Material:
+    """new Material(Shader.Find("Hidden/AdditionShader")) (RM:813-815)."""
+
+    def __init__(self, shader_name: str = "Hidden/AdditionShader"):
+        if shader_name != "Hidden/AdditionShader":
+            raise UrtError(1, f"Shader.Find: {shader_name} not found")
+        self.floats = {"_Sample": 0.0}
+
+    def SetFloat(self, name: str, v: float):
+        self.floats[name] = float(v)
+
+
+class Graphics:
+    @staticmethod
+    def Blit(source: RenderTexture, dest: RenderTexture, mat: Material | None = None):
+        """Graphics.Blit(src, dst[, additionMaterial]) — RM:818-819."""
+        ctx = source.ctx
+        if mat is None:
+            ctx.check(ctx.lib.urt_blit(ctx._h, source.handle, dest.handle))
+        else:
+            ctx.check(ctx.lib.urt_blit_add(ctx._h, source.handle, dest.handle, mat.floats["_Sample"]))
+
+
+def debug_build_blas(mesh_objects: np.ndarray, vertices: np.ndarray, indices: np.ndarray):
+    """Run the library's triangle-BVH builder on host arrays (no GPU needed) and return
+    (nodes[n,16] f32, tri_index[n_tris] i32, mesh_root[n_meshes] i32, mesh_first_tri, max_depth)."""
+    lib = _lib.load()
+    mo = np.ascontiguousarray(mesh_objects)
+    v = np.ascontiguousarray(vertices, dtype=np.float32)
+    ix = np.ascontiguousarray(indices, dtype=np.int32)
+    nn, nt, md = C.c_int(), C.c_int(), C.c_int()
+    rc = lib.urt_debug_build_blas(mo.ctypes.data_as(C.c_void_p), len(mo), v.ctypes.data_as(C.c_void_p), len(v.reshape(-1, 3)),
+                                  ix.ctypes.data_as(C.c_void_p), ix.size, C.byref(nn), C.byref(nt), C.byref(md))
+    if rc != 0:
+        raise UrtError(rc, lib.urt_last_error(None).decode())
+    nodes = np.zeros((nn.value, 16), dtype=np.float32)
+    tri = np.zeros(nt.value, dtype=np.int32)
+    root = np.zeros(len(mo), dtype=np.int32)
+    first = np.zeros(len(mo), dtype=np.int32)
+    lib.urt_debug_get_blas(nodes.ctypes.data_as(C.c_void_p), tri.ctypes.data_as(C.c_void_p), root.ctypes.data_as(C.c_void_p),
+                           first.ctypes.data_as(C.c_void_p))
+    return nodes, tri, root, first, md.value
