@@ -319,7 +319,9 @@ struct Tracer {
         }
       }
       for (int i = 0; i < tests; i++) {
+        OracleCounters save = C;
         if (node.index >= 0 && node.index < S.n_mesh_objects) IntersectMeshObject(ray, bestHit, node.index);
+        if (i > 0) C = save;   // a repeat changes nothing (strict '<', A.5): count the work once, as the product does it once
       }
     }
   }
@@ -348,7 +350,9 @@ struct Tracer {
         }
       }
       for (int i = 0; i < tests; i++) {
+        OracleCounters save = C;
         if (node.index >= 0 && node.index < S.n_spheres) IntersectSphere(ray, bestHit, S.spheres[node.index]);
+        if (i > 0) C = save;
       }
     }
   }

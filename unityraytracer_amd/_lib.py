@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libunityraytracer_amd.so")
+LIB_PATH = os.environ.get("URT_LIB_PATH") or os.path.join(_HERE, "libunityraytracer_amd.so")   # override: A/B builds in experiments
 
 URT_OK = 0
 ERROR_NAMES = {1: "INVALID_ARGUMENT", 2: "INVALID_HANDLE", 3: "NO_DEVICE", 4: "HIP", 5: "UNBOUND", 6: "LAYOUT", 7: "OUT_OF_MEMORY", 8: "SCENE"}

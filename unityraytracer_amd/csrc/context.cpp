@@ -107,6 +107,7 @@ int fail(urt_context* ctx, int code, const std::string& msg) {
   catch (...) { return fail(ctx, URT_ERR_INVALID_ARGUMENT, "unknown exception"); }
 
 void free_scene(urt_context* ctx) {
+  if (!ctx->scene_allocs.empty()) (void)hipStreamSynchronize(ctx->stream);   // queued kernels may still read them
   for (void* p : ctx->scene_allocs) (void)hipFree(p);
   ctx->scene_allocs.clear();
   ctx->ds = DevScene{};
@@ -119,7 +120,9 @@ int upload(urt_context* ctx, const std::vector<T>& v, const float4** out) {
   void* d = nullptr;
   URT_HIP(ctx, hipMalloc(&d, v.size() * sizeof(T)));
   ctx->scene_allocs.push_back(d);
-  URT_HIP(ctx, hipMemcpyAsync(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+  // synchronous on purpose: `v` is a short-lived staging vector, and a pageable-memory hipMemcpyAsync may
+  // still be reading it after this function returns
+  URT_HIP(ctx, hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
   *out = (const float4*)d;
   return URT_OK;
 }
