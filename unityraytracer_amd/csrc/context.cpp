@@ -83,6 +83,7 @@ struct urt_context {
   float trace_ms = 0;
 
   int opt_count_stats = 0, opt_time_dispatch = 0, opt_kernel_mode = 1;
+  int opt_block_threads = 256, opt_xcd_run = 1;
 };
 
 namespace {
@@ -170,8 +171,10 @@ int prepare_scene(urt_context* ctx) {
   const Buffer* bst = bound_buffer(ctx, B_SPHEREBVH);
 
   int rc;
-  // meshes
   int n_meshes = bm ? bm->count : 0;
+  int n_spheres = bs ? bs->count : 0;
+  std::vector<float> mats((size_t)(n_meshes + n_spheres) * 12);   // spheres first, then mesh objects
+  // meshes
   BlasResult blas;
   if (n_meshes > 0) {
     std::string err;
@@ -179,14 +182,12 @@ int prepare_scene(urt_context* ctx) {
                     bi ? (const int32_t*)bi->host.data() : nullptr, bi ? bi->count : 0,
                     bn ? (const float*)bn->host.data() : nullptr, bn ? bn->count : 0, blas, err))
       return fail(ctx, URT_ERR_SCENE, err);
-    std::vector<float> mats((size_t)n_meshes * 12);
     for (int m = 0; m < n_meshes; m++) {
       urt_MeshObject mo;
       std::memcpy(&mo, bm->host.data() + (size_t)m * URT_STRIDE_MESHOBJECT, sizeof mo);
-      pack_material(mo.lighting, mats.data() + (size_t)m * 12);
+      pack_material(mo.lighting, mats.data() + (size_t)(n_spheres + m) * 12);
     }
     const float4* p;
-    if ((rc = upload(ctx, mats, &p))) return rc; S.mesh_mat = p;
     if ((rc = upload(ctx, blas.mesh_root, &p))) return rc; S.mesh_root = (const int32_t*)p;
     if ((rc = upload(ctx, blas.nodes, &p))) return rc; S.blas_nodes = p;
     if ((rc = upload(ctx, blas.tri_verts, &p))) return rc; S.tri_verts = p;
@@ -194,9 +195,8 @@ int prepare_scene(urt_context* ctx) {
   }
   S.n_meshes = n_meshes;
   // spheres
-  int n_spheres = bs ? bs->count : 0;
   if (n_spheres > 0) {
-    std::vector<float> pr((size_t)n_spheres * 4), mats((size_t)n_spheres * 12);
+    std::vector<float> pr((size_t)n_spheres * 4);
     for (int i = 0; i < n_spheres; i++) {
       urt_Sphere sp;
       std::memcpy(&sp, bs->host.data() + (size_t)i * URT_STRIDE_SPHERE, sizeof sp);
@@ -206,7 +206,10 @@ int prepare_scene(urt_context* ctx) {
     }
     const float4* p;
     if ((rc = upload(ctx, pr, &p))) return rc; S.sphere_pr = p;
-    if ((rc = upload(ctx, mats, &p))) return rc; S.sphere_mat = p;
+  }
+  {
+    const float4* p;
+    if ((rc = upload(ctx, mats, &p))) return rc; S.materials = p;
   }
   S.n_spheres = n_spheres;
   // object-level BVHs
@@ -223,7 +226,7 @@ int prepare_scene(urt_context* ctx) {
     return fail(ctx, URT_ERR_SCENE, "object-level BVH deeper than the reference's 32-entry traversal stack (RS:73-74)");
   ctx->tlas_stack = std::max(2, lv + 1);
   ctx->blas_stack = std::max(2, blas.max_depth + 1);
-  if ((size_t)(ctx->tlas_stack + ctx->blas_stack) * 64 * 4 * sizeof(int) > 64 * 1024)
+  if ((size_t)(ctx->tlas_stack + ctx->blas_stack) * 64 * 4 * sizeof(int) > 64 * 1024)   // at the largest workgroup (4 waves)
     return fail(ctx, URT_ERR_SCENE, "traversal stacks exceed the 64 KiB LDS budget per workgroup");
   ctx->scene_dirty = false;
   return URT_OK;
@@ -303,6 +306,7 @@ int do_dispatch(urt_context* ctx, int kernel, int gx, int gy, int gz, int first_
   P.first_group_row = first_row; P.row_stride = row_stride;
   P.n_strips = first_row < group_rows ? (group_rows - first_row + row_stride - 1) / row_stride : 0;
   P.tlas_stack = ctx->tlas_stack; P.blas_stack = ctx->blas_stack;
+  P.block_threads = ctx->opt_block_threads; P.xcd_run = ctx->opt_xcd_run;
   if (P.n_strips == 0 || P.tiles_x == 0) return URT_OK;
 
   bool wavefront = ctx->opt_kernel_mode == 1 && P.num_bounces > 0 && P.num_rays > 0;
@@ -534,8 +538,7 @@ int urt_shader_set_buffer(urt_context* ctx, int kernel, const char* name, urt_ha
         return fail(ctx, URT_ERR_LAYOUT, std::string("SetBuffer(") + name + "): stride " + std::to_string(it->second.stride) +
                                              " != " + std::to_string(kBindStride[s]) + " (RM:738-745)");
     }
-    if (ctx->bound[s] != buffer) { ctx->bound[s] = buffer; }
-    ctx->scene_dirty = true;
+    if (ctx->bound[s] != buffer) { ctx->bound[s] = buffer; ctx->scene_dirty = true; }   // re-binding the same buffer every frame (RM:787-794) is free
     return URT_OK;
   }
   return fail(ctx, URT_ERR_INVALID_ARGUMENT, std::string("SetBuffer: kernel CSMain has no buffer named ") + name);
@@ -653,6 +656,12 @@ int urt_set_option(urt_context* ctx, const char* name, int value) {
   else if (std::strcmp(name, "kernel_mode") == 0) {
     if (value != 0 && value != 1) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "kernel_mode must be 0 or 1");
     ctx->opt_kernel_mode = value;
+  } else if (std::strcmp(name, "block_threads") == 0) {
+    if (value != 64 && value != 128 && value != 256) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "block_threads must be 64, 128 or 256");
+    ctx->opt_block_threads = value;
+  } else if (std::strcmp(name, "xcd_run") == 0) {
+    if (value < 1 || value > 4096) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "xcd_run must be in [1, 4096]");
+    ctx->opt_xcd_run = value;
   } else return fail(ctx, URT_ERR_INVALID_ARGUMENT, std::string("unknown option ") + name);
   return URT_OK;
 }

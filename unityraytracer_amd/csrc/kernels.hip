@@ -265,20 +265,21 @@ __device__ __forceinline__ bool shade(const DevScene& S, const HitRec& h, v3& o,
       n = mk3(0, 1, 0);
       albedo = mk3(0.5f, 0.3f, 0.15f); spec = mk3(0, 0, 0); emission = mk3(0, 0, 0); smooth = 0.3f;
     } else {
-      const float4* m;
+      // one material table: spheres first, then mesh objects (an integer select, no pointer select)
+      int mat;
       if (h.kind == 2) {                     // RS:192-194
         if (COUNT) lc.hit_sphere++;
         n = normalize(pos - xyz(S.sphere_pr[h.id]));
-        m = S.sphere_mat + 3 * (size_t)h.id;
+        mat = h.id;
       } else {                               // RS:259-264
         if (COUNT) lc.hit_tri++;
         const float4* tn = S.tri_norms + 3 * (size_t)h.id;
         v3 n0 = xyz(tn[0]), n1 = xyz(tn[1]), n2 = xyz(tn[2]);
         float w = 1.0f - h.u - h.v;
         n = normalize((n0 * w) + (n1 * h.u) + (n2 * h.v));
-        int mesh = as_int(S.tri_verts[3 * (size_t)h.id + 1].w);
-        m = S.mesh_mat + 3 * (size_t)mesh;
+        mat = S.n_spheres + as_int(S.tri_verts[3 * (size_t)h.id + 1].w);
       }
+      const float4* m = S.materials + 3 * (size_t)mat;
       float4 m0 = m[0], m1 = m[1], m2 = m[2];
       albedo = xyz(m0); smooth = m0.w; spec = xyz(m1); emission = xyz(m2);
     }
@@ -330,14 +331,15 @@ __device__ __forceinline__ void camera_ray(const FrameParams& P, int x, int y, f
 }
 
 // tile -> pixel: one 8x8 tile per wave (the reference's [numthreads(8,8,1)] group, RS:431).
-// Blocks are dealt round-robin to the 8 XCDs (b % 8 shares an XCD): give each XCD a contiguous
-// band of tiles so that its private L2 serves one part of the scene.
+// Blocks are dealt round-robin to the 8 XCDs (b % 8 shares an XCD, each XCD has a private 4 MiB L2).
+// xcd_run = G makes every XCD walk runs of G consecutive blocks (G * waves-per-block adjacent tiles):
+// G = 1 is plain linear order, large G approaches one contiguous image band per XCD (best L2 locality,
+// worst load balance: sky bands finish early).  Only speed depends on it, never results.
 __device__ __forceinline__ bool tile_pixel(const FrameParams& P, int& x, int& y) {
   int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  int nblocks = gridDim.x;
   int b = blockIdx.x;
-  int per_xcd = (nblocks + 7) >> 3;
-  int sb = (b & 7) * per_xcd + (b >> 3);          // swizzled block id in [0, 8*per_xcd)
+  int G = P.xcd_run;
+  int sb = ((b / (8 * G)) * 8 + (b & 7)) * G + ((b >> 3) % G);
   int tile = sb * (blockDim.x >> 6) + wave;
   int ntiles = P.tiles_x * P.n_strips;
   if (tile >= ntiles) return false;
@@ -545,17 +547,23 @@ __global__ __launch_bounds__(256) void k_pack_rows(const float4* __restrict__ im
 namespace urtd {
 
 static inline int blocks_for_tiles(const FrameParams& P) {
+  int waves = P.block_threads / 64;
   int ntiles = P.tiles_x * P.n_strips;
-  int nblocks = (ntiles + 3) / 4;
-  return ((nblocks + 7) / 8) * 8;   // multiple of 8 so the XCD swizzle is a bijection onto [0, nblocks)
+  int nblocks = (ntiles + waves - 1) / waves;
+  int q = 8 * P.xcd_run;                      // the block permutation of tile_pixel() acts on windows of 8*G blocks
+  return ((nblocks + q - 1) / q) * q;
+}
+
+static inline size_t stack_lds_bytes(const FrameParams& P) {
+  return (size_t)(P.tlas_stack + P.blas_stack) * 64 * (size_t)(P.block_threads / 64) * sizeof(int);
 }
 
 hipError_t launch_mega(const DevScene& S, const FrameParams& P, float4* result, DevCounters* ctr, bool count, hipStream_t st) {
   int nb = blocks_for_tiles(P);
   if (nb == 0) return hipSuccess;
-  size_t lds = (size_t)(P.tlas_stack + P.blas_stack) * 64 * 4 * sizeof(int);
-  if (count) hipLaunchKernelGGL(k_mega<true>, dim3(nb), dim3(256), lds, st, S, P, result, ctr);
-  else hipLaunchKernelGGL(k_mega<false>, dim3(nb), dim3(256), lds, st, S, P, result, ctr);
+  size_t lds = stack_lds_bytes(P);
+  if (count) hipLaunchKernelGGL(k_mega<true>, dim3(nb), dim3(P.block_threads), lds, st, S, P, result, ctr);
+  else hipLaunchKernelGGL(k_mega<false>, dim3(nb), dim3(P.block_threads), lds, st, S, P, result, ctr);
   return hipGetLastError();
 }
 
@@ -563,17 +571,18 @@ hipError_t launch_wavefront(const DevScene& S, const FrameParams& P, const PathQ
                             bool count, hipStream_t st) {
   int nb = blocks_for_tiles(P);
   if (nb == 0) return hipSuccess;
-  size_t lds = (size_t)(P.tlas_stack + P.blas_stack) * 64 * 4 * sizeof(int);
+  size_t lds = stack_lds_bytes(P);
   size_t n_counts = (size_t)P.num_rays * (P.num_bounces + 1);
   hipError_t e = hipMemsetAsync(Q.counts, 0, n_counts * sizeof(unsigned int), st);
   if (e != hipSuccess) return e;
   size_t npix = (size_t)P.region_w * 8 * P.n_strips;
-  int nbb = (int)((npix + 255) / 256);
+  int bt = P.block_threads;
+  int nbb = (int)((npix + bt - 1) / bt);
   for (int i = 0; i < P.num_rays; i++) {
-    hipLaunchKernelGGL(k_generate, dim3(nb), dim3(256), 0, st, P, Q, (const float4*)result, i, ctr);
+    hipLaunchKernelGGL(k_generate, dim3(nb), dim3(bt), 0, st, P, Q, (const float4*)result, i, ctr);
     for (int k = 0; k < P.num_bounces; k++) {
-      if (count) hipLaunchKernelGGL(k_bounce<true>, dim3(nbb), dim3(256), lds, st, S, P, Q, result, i, k, ctr);
-      else hipLaunchKernelGGL(k_bounce<false>, dim3(nbb), dim3(256), lds, st, S, P, Q, result, i, k, ctr);
+      if (count) hipLaunchKernelGGL(k_bounce<true>, dim3(nbb), dim3(bt), lds, st, S, P, Q, result, i, k, ctr);
+      else hipLaunchKernelGGL(k_bounce<false>, dim3(nbb), dim3(bt), lds, st, S, P, Q, result, i, k, ctr);
     }
   }
   return hipGetLastError();

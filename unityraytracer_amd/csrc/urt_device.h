@@ -22,10 +22,11 @@ struct DevScene {
   const float4* sphere_tlas; int n_sphere_tlas;
   // spheres (RS:51-55): position.xyz + radius; materials as 3 x float4
   const float4* sphere_pr;   int n_spheres;
-  const float4* sphere_mat;  // [3i] albedo.xyz, smoothness  [3i+1] specular.xyz, 0  [3i+2] emission.xyz, 0
+  // materials (RS:29-34) of the spheres [0, n_spheres) then of the mesh objects, 3 x float4 each:
+  //   [3i] albedo.xyz, smoothness  [3i+1] specular.xyz, 0  [3i+2] emission.xyz, 0
+  const float4* materials;
   // mesh objects (RS:43-49)
   const int32_t* mesh_root;  int n_meshes;
-  const float4* mesh_mat;    // same 3 x float4 form
   // triangle BVH over world-space triangles, all meshes in one pool
   const float4* blas_nodes;  // 4 x float4 per node
   const float4* tri_verts;   // [3k] v0.xyz, index slot i (int bits)  [3k+1] e1.xyz, mesh id (int bits)  [3k+2] e2.xyz, 0
@@ -49,6 +50,8 @@ struct FrameParams {
   int n_strips;             // local strips (8 pixel rows each)
   int tlas_stack;           // LDS entries per lane reserved for the object-level stacks
   int blas_stack;           // LDS entries per lane reserved for the triangle-BVH stack
+  int block_threads;        // workgroup size (64, 128 or 256)
+  int xcd_run;              // blocks per XCD run in the tile order (kernels.hip tile_pixel)
 };
 
 struct DevCounters {       // 64-bit device counters, accumulated with atomics
