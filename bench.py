@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the path-tracing hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): Mrays/sec @1920x1080, 8 bounces.  A *ray* is one Trace() invocation
+(RayTraceShader.compute:454), counted by the kernels themselves; a *step* is one frame of the reference's
+frame protocol (RayTraceMaster.OnRenderImage: set uniforms -> Dispatch -> AdditionShader blit), with
+every input already resident in HBM.  Workload at N=1: config C3 of BASELINE.json (bunny-class 69,600-triangle
+mesh + triangle BVH, 1920x1080, numBounces 8, numRays 1, synthetic scene from unityraytracer_amd.scenes).
+
+Multi-GPU (weak scaling): one process per GPU; the frame grows to N x (1920x1080) pixels at the same
+aspect and camera (N=4 is 3840x2160, BASELINE's multi-GPU resolution), cut into 8-row strips dealt
+round-robin to the ranks (global pixel ids -> pixels identical to a single-GPU frame); each rank
+accumulates its strips locally and ONE gather per frame (RCCL via torch.distributed) brings them to rank 0.
+
+Rank 0 prints one JSON line.  Extra objects: `roofline` (dominant kernel = the trace kernel: algorithmic
+bytes from the kernels' own traversal counters / its HIP-event duration, against 8 TB/s HBM) and
+`cpu_baseline` (the scalar C++ oracle — a port, not the reference — timed on the host cores for a bounded
+sample of the same workload).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+# algorithmic bytes per counted event (DESIGN.md "roofline")
+BYTES = {"tlas_nodes": 28, "blas_nodes": 64, "tri_tests": 48, "sphere_tests": 16, "hit_tri": 88, "hit_sphere": 40,
+         "hit_sky": 64, "pixels": 16}
+
+
+def algorithmic_bytes(c: dict) -> int:
+    return sum(BYTES[k] * int(c[k]) for k in BYTES)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="C3", help="BASELINE.json config to trace (C2..C5); the metric is quoted on C3")
+    ap.add_argument("--kernel-mode", type=int, default=None, help="0 per-pixel, 1 per-bounce queues, 2 persistent (default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+
+    from unityraytracer_amd import Context, RayTraceMaster, scenes, strips
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    # ---- workload --------------------------------------------------------------------------------
+    base_w, base_h = (1920, 1080) if args.config in ("C2", "C3") else (3840, 2160)
+    s = math.sqrt(world) if args.config in ("C2", "C3") else math.sqrt(world / 8.0) if world > 1 else 1.0
+    width, height = int(round(base_w * s)), int(round(base_h * s))
+    scene = scenes.CONFIGS[args.config](width, height)
+
+    ctx = Context(local_rank)
+    ctx.set_stream(torch.cuda.current_stream(device).cuda_stream)      # one in-order stream for kernels + collective
+    if args.kernel_mode is not None:
+        ctx.set_option("kernel_mode", args.kernel_mode)
+    ctx.set_option("time_dispatch", 1)
+    master = RayTraceMaster(ctx, scene, rank=rank, world_size=world)
+
+    packed = None
+    if world > 1:
+        n_floats = strips.packed_rows(height, world) * width * 4
+        packed = torch.zeros(n_floats, dtype=torch.float32, device=device)
+        gathered = [torch.empty_like(packed) for _ in range(world)] if rank == 0 else None
+        full = None
+        if rank == 0:
+            from unityraytracer_amd import RenderTexture
+            full = RenderTexture(ctx, width, height)
+
+    def step():
+        master.OnRenderImage()
+        if world > 1:
+            master._converged.pack_rows(rank, world, packed.data_ptr())
+            dist.gather(packed, gathered, dst=0)
+            if rank == 0:
+                for r in range(world):
+                    full.unpack_rows(r, world, gathered[r].data_ptr())
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ctx.reset_counters()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    c = ctx.counters()
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    rays = torch.tensor([float(c["rays"])], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(rays, op=dist.ReduceOp.SUM)
+    elapsed = float(t.item())
+    total_rays = float(rays.item())
+
+    # ---- roofline of the dominant kernel (rank 0): replay the same frames with traversal counters on -----------
+    roofline = None
+    cpu = None
+    if rank == 0:
+        kernel_ms = c["trace_ms"] / max(1, c["dispatches"])
+        ctx.set_option("count_stats", 1)
+        ctx.set_option("time_dispatch", 0)
+        master._frame = args.warmup
+        ctx.reset_counters()
+        for _ in range(args.steps):
+            master.OnRenderImage()
+        cc = ctx.counters()
+        ctx.set_option("count_stats", 0)
+        assert cc["rays"] == c["rays"], "counting replay traced a different number of rays"
+        alg = algorithmic_bytes(cc) / max(1, cc["dispatches"])
+        achieved = alg / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")       # written from rocprofv3 --pmc passes (profiles/README.md)
+        if os.path.exists(pmc):
+            try:
+                j = json.load(open(pmc))
+                if j.get("config") == args.config and world == 1:
+                    traffic = j.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": "trace (k_persist / k_mega / k_bounce by kernel_mode)", "achieved": round(achieved, 1),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "algorithmic_bytes_per_launch": int(alg), "kernel_ms": round(kernel_ms, 4),
+                    "bytes_per_ray": round(alg * cc["dispatches"] / max(1, cc["rays"]), 1)}
+
+        # ---- CPU baseline: the oracle (scalar C++ port) on the host cores, bounded sample -------------------------
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import pyoracle
+            from unityraytracer_amd import debug_build_blas
+            o = pyoracle.Oracle(scene)
+            if len(scene.mesh_objects):
+                nodes, tri, root, _, _ = debug_build_blas(scene.mesh_objects, scene.vertices, scene.indices)
+                o.set_blas(nodes, tri, root)
+            cores = min(pyoracle.hardware_threads(), len(os.sched_getaffinity(0)))
+            tc = time.perf_counter()
+            _, oc = o.render(mode=1, threads=cores, counters=True)
+            dt = time.perf_counter() - tc
+            cpu = {"value": round(oc["rays"] / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+                   "sample": f"1 frame of {scene.name} {width}x{height} (frame 0 uniforms), BVH-culled scalar oracle, {cores} std::threads"}
+
+    if rank == 0:
+        out = {
+            "metric": "Mrays/sec @1920x1080, 8 bounces", "value": round(total_rays / elapsed / 1e6, 2), "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {scene.name}, {scene.n_triangles} triangles + triangle BVH, {len(scene.spheres)} spheres, "
+                                   f"ground plane, equirect sky; numBounces {scene.num_bounces}, numRays {scene.num_rays}",
+                       "frame": [width, height], "pixels_per_gpu": width * height // world,
+                       "partition": "8-row strips round-robin over ranks, one gather per frame" if world > 1 else "single GPU",
+                       "rays_per_step": int(total_rays / args.steps), "kernel_mode": args.kernel_mode if args.kernel_mode is not None else 2},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    master.OnDisable()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

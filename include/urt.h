@@ -143,9 +143,10 @@ typedef struct urt_counters {
 } urt_counters;
 /* Options: "count_stats" (0/1: per-dispatch traversal counters, slower build of the kernel),
  *          "time_dispatch" (0/1: bracket each dispatch with HIP events, read by urt_get_counters),
- *          "kernel_mode" (0 = per-pixel megakernel, 1 = wavefront with ray compaction; default 1),
- *          "block_threads" (64 | 128 | 256 lanes per workgroup), "xcd_run" (blocks per XCD run in the
- *          tile order, >= 1) — tuning knobs; they change speed only, never pixels. */
+ *          "kernel_mode" (0 = one thread per pixel; 1 = one launch per bounce over compacted path queues;
+ *                         2 = persistent waves with in-wave path regeneration, the default),
+ *          "block_threads" (64 | 128 | 256), "xcd_run" (>= 1), "refill_min" (1..64), "waves_per_cu" (1..32)
+ *          — tuning knobs; they change speed only, never pixels. */
 URT_API int urt_set_option(urt_context* ctx, const char* name, int value);
 URT_API int urt_get_counters(urt_context* ctx, urt_counters* out);   /* synchronises */
 URT_API int urt_reset_counters(urt_context* ctx);

@@ -1,0 +1,65 @@
+"""The C-ABI library loads, exports every symbol include/urt.h declares, and refuses to work without a GPU
+(no CPU fallback).  No compute entry point is called here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import unityraytracer_amd as urt
+from unityraytracer_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "urt.h")).read()
+    return sorted(set(re.findall(r"URT_API\s+[\w\s\*]+?\b(urt_\w+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    assert header_symbols() == sorted(_lib.ABI_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol(built_library):
+    lib = C.CDLL(built_library)
+    for name in header_symbols():
+        assert hasattr(lib, name), f"{name} is declared in include/urt.h but not exported"
+    assert _lib.load().urt_abi_version() == 1
+
+
+def test_layout_strides_match_reference():
+    # RayTraceMaster.cs:42-45
+    assert urt.scenes.PARAMS_DT.itemsize == 40 and urt.scenes.MESHOBJECT_DT.itemsize == 112
+    assert urt.scenes.SPHERE_DT.itemsize == 56 and urt.scenes.BVHNODE_DT.itemsize == 28
+    assert urt.scenes.MESHOBJECT_DT.fields["indices_offset"][1] == 64 and urt.scenes.MESHOBJECT_DT.fields["lighting"][1] == 72
+    assert urt.scenes.SPHERE_DT.fields["radius"][1] == 12 and urt.scenes.BVHNODE_DT.fields["index"][1] == 24
+
+
+def test_no_cpu_fallback(built_library):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(urt.UrtError) as e:
+        urt.Context(0)
+    assert e.value.code == 3 and "no CPU fallback" in str(e.value)      # URT_ERR_NO_DEVICE
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(ImportError):
+        _lib.load()
+
+
+def test_product_never_touches_the_oracle():
+    """The shipped path must not import, include, link or load anything under oracle/ (comments may cite it)."""
+    pkg = os.path.join(ROOT, "unityraytracer_amd")
+    bad = re.compile(r"import\s+oracle|from\s+oracle|pyoracle|liboracle|#include\s*[\"<][^\">]*oracle|dlopen[^\n]*oracle")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert not bad.search(text), f"{f} references the oracle"
+    for f in os.listdir(os.path.join(ROOT, "include")):
+        assert not bad.search(open(os.path.join(ROOT, "include", f)).read()), f

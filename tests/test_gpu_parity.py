@@ -43,7 +43,7 @@ def oracle_for(scene, use_product_blas=True):
     return o
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 2])
 def test_mixed_scene_bit_exact(gpu_ctx, mode):
     sc = scenes.mixed_test_scene(200, 120)           # ragged: not a multiple of 8
     o = oracle_for(sc)
@@ -54,7 +54,7 @@ def test_mixed_scene_bit_exact(gpu_ctx, mode):
         assert gc[k] == oc[k], (k, gc[k], oc[k])
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 2])
 def test_config1_spheres_bit_exact(gpu_ctx, mode):
     sc = scenes.config1()
     ref = pyoracle.Oracle(sc).render(mode=0, threads=8)
@@ -66,8 +66,9 @@ def test_config3_mesh_quarter_res_bit_exact(gpu_ctx):
     sc = scenes.config3(480, 270, sky=scenes.make_sky(512, 256))
     o = oracle_for(sc)
     ref = o.render(mode=1, threads=8)
-    gpu, _, _ = render_gpu(gpu_ctx, sc, 1)
-    assert_same(gpu, ref, "C3 480x270")
+    for mode in (2, 1):
+        gpu, _, _ = render_gpu(gpu_ctx, sc, mode)
+        assert_same(gpu, ref, f"C3 480x270 mode {mode}")
     # and the literal brute-force loop of RS:243 on a crop through the mesh
     rect = (220, 120, 252, 136)
     brute = o.render(rect=rect, mode=0, threads=8)
@@ -83,7 +84,7 @@ def test_multi_ray_multi_frame_accumulation(gpu_ctx):
         ox, oy, seed = scenes.frame_uniforms(f)
         o.set_frame((ox, oy), seed)
         conv_ref = pyoracle.accumulate(o.render(mode=1, threads=8), conv_ref, f)
-    for mode in (0, 1):
+    for mode in (0, 1, 2):
         _, conv, _ = render_gpu(gpu_ctx, sc, mode, frames=3)
         assert_same(conv, conv_ref, f"3-frame running mean, mode {mode}")
 
@@ -91,11 +92,11 @@ def test_multi_ray_multi_frame_accumulation(gpu_ctx):
 def test_strips_union_equals_full_frame(gpu_ctx):
     """dispatch_rows(r, N) for r = 0..N-1 writes exactly the pixels of one full dispatch (global ids)."""
     sc = scenes.mixed_test_scene(120, 100)
-    full, _, _ = render_gpu(gpu_ctx, sc, 1)
+    full, _, _ = render_gpu(gpu_ctx, sc, 2)
     world = 3
     union = np.zeros_like(full)
     for r in range(world):
-        gpu_ctx.set_option("kernel_mode", 1)
+        gpu_ctx.set_option("kernel_mode", 2)
         m = RayTraceMaster(gpu_ctx, sc, rank=r, world_size=world)
         m.OnRenderImage()
         part = m._target.GetPixels()

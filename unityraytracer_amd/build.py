@@ -1,4 +1,4 @@
-"""Build recipes (in-tree, explicit hipcc — no JIT cache): the HIP library and the test-only oracle."""
+"""Build recipe of the product (in-tree, explicit hipcc — no JIT cache): the HIP library behind include/urt.h."""
 from __future__ import annotations
 
 import os
@@ -42,15 +42,5 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
-def build_oracle(force: bool = False) -> str:
-    """make -C oracle -> oracle/liboracle.so (g++, -ffp-contract=off).  Test infrastructure only."""
-    odir = os.path.join(_ROOT, "oracle")
-    if force:
-        subprocess.run(["make", "-C", odir, "clean"], check=True, stdout=subprocess.DEVNULL)
-    subprocess.run(["make", "-C", odir], check=True, stdout=subprocess.DEVNULL)
-    return os.path.join(odir, "liboracle.so")
-
-
 if __name__ == "__main__":
     print(build_library(force=True, verbose=True))
-    print(build_oracle())

@@ -77,13 +77,16 @@ struct urt_context {
   PathQueues q{};
   size_t q_capacity = 0, counts_capacity = 0;
 
-  DevCounters* d_counters = nullptr;
+  DevCounters* d_counters = nullptr;        // kCounterShards shards
+  unsigned int* d_next = nullptr;           // persistent mode: frame work counter
+  uint64_t pixels_dispatched = 0;
+  int n_cus = 256;
   uint64_t dispatches = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> timing;   // unresolved event pairs
   float trace_ms = 0;
 
-  int opt_count_stats = 0, opt_time_dispatch = 0, opt_kernel_mode = 1;
-  int opt_block_threads = 256, opt_xcd_run = 1;
+  int opt_count_stats = 0, opt_time_dispatch = 0, opt_kernel_mode = 2;
+  int opt_block_threads = 64, opt_xcd_run = 1, opt_refill_min = 16, opt_waves_per_cu = 16;
 };
 
 namespace {
@@ -306,11 +309,21 @@ int do_dispatch(urt_context* ctx, int kernel, int gx, int gy, int gz, int first_
   P.first_group_row = first_row; P.row_stride = row_stride;
   P.n_strips = first_row < group_rows ? (group_rows - first_row + row_stride - 1) / row_stride : 0;
   P.tlas_stack = ctx->tlas_stack; P.blas_stack = ctx->blas_stack;
-  P.block_threads = ctx->opt_block_threads; P.xcd_run = ctx->opt_xcd_run;
+  P.block_threads = ctx->opt_block_threads; P.xcd_run = ctx->opt_xcd_run; P.refill_min = ctx->opt_refill_min;
   if (P.n_strips == 0 || P.tiles_x == 0) return URT_OK;
 
-  bool wavefront = ctx->opt_kernel_mode == 1 && P.num_bounces > 0 && P.num_rays > 0;
-  if (wavefront) {
+  // region pixels this dispatch writes (threads outside Result write nothing, RS:468)
+  {
+    uint64_t px = 0;
+    for (int j = 0; j < P.n_strips; j++) {
+      int y0 = (first_row + j * row_stride) * 8;
+      px += (uint64_t)std::max(0, std::min(P.region_h - y0, 8)) * (uint64_t)P.region_w;
+    }
+    ctx->pixels_dispatched += px;
+  }
+  bool degenerate = P.num_bounces <= 0 || P.num_rays <= 0;      // loops that never run: the megakernel handles them literally
+  int mode = degenerate ? 0 : ctx->opt_kernel_mode;
+  if (mode == 1) {
     size_t n_paths = (size_t)P.tiles_x * 64 * (size_t)P.n_strips;
     int rc = ensure_queues(ctx, n_paths, (size_t)P.num_rays * (size_t)(P.num_bounces + 1));
     if (rc) return rc;
@@ -321,8 +334,15 @@ int do_dispatch(urt_context* ctx, int kernel, int gx, int gy, int gz, int first_
     URT_HIP(ctx, hipEventCreate(&e1));
     URT_HIP(ctx, hipEventRecord(e0, ctx->stream));
   }
-  hipError_t le = wavefront ? launch_wavefront(S, P, ctx->q, res->dev, ctx->d_counters, ctx->opt_count_stats != 0, ctx->stream)
-                            : launch_mega(S, P, res->dev, ctx->d_counters, ctx->opt_count_stats != 0, ctx->stream);
+  bool count = ctx->opt_count_stats != 0;
+  hipError_t le;
+  if (mode == 1) le = launch_wavefront(S, P, ctx->q, res->dev, ctx->d_counters, count, ctx->stream);
+  else if (mode == 2) {
+    int waves_per_block = P.block_threads / 64;
+    long want = ((long)P.tiles_x * P.n_strips + waves_per_block - 1) / waves_per_block;
+    long resident = (long)ctx->n_cus * ctx->opt_waves_per_cu / waves_per_block;
+    le = launch_persist(S, P, res->dev, ctx->d_counters, ctx->d_next, (int)std::max(1L, std::min(want, resident)), count, ctx->stream);
+  } else le = launch_mega(S, P, res->dev, ctx->d_counters, count, ctx->stream);
   if (ctx->opt_time_dispatch) {
     (void)hipEventRecord(e1, ctx->stream);
     ctx->timing.emplace_back(e0, e1);
@@ -361,8 +381,10 @@ int urt_context_create(int device, urt_context** out_ctx) {
   e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete ctx; return fail(nullptr, URT_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
   ctx->stream = ctx->own_stream;
-  e = hipMalloc((void**)&ctx->d_counters, sizeof(DevCounters));
-  if (e == hipSuccess) e = hipMemset(ctx->d_counters, 0, sizeof(DevCounters));
+  e = hipMalloc((void**)&ctx->d_counters, sizeof(DevCounters) * kCounterShards);
+  if (e == hipSuccess) e = hipMemset(ctx->d_counters, 0, sizeof(DevCounters) * kCounterShards);
+  if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_next, sizeof(unsigned int));
+  if (e == hipSuccess) { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n > 0) ctx->n_cus = n; }
   if (e != hipSuccess) { (void)hipStreamDestroy(ctx->own_stream); delete ctx; return fail(nullptr, URT_ERR_HIP, std::string("counter allocation: ") + hipGetErrorString(e)); }
   *out_ctx = ctx;
   return URT_OK;
@@ -380,6 +402,7 @@ int urt_context_destroy(urt_context* ctx) {
   if (ctx->q.counts) (void)hipFree(ctx->q.counts);
   if (ctx->zero_sky) (void)hipFree(ctx->zero_sky);
   if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+  if (ctx->d_next) (void)hipFree(ctx->d_next);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
   return URT_OK;
@@ -654,11 +677,17 @@ int urt_set_option(urt_context* ctx, const char* name, int value) {
   if (std::strcmp(name, "count_stats") == 0) ctx->opt_count_stats = value ? 1 : 0;
   else if (std::strcmp(name, "time_dispatch") == 0) ctx->opt_time_dispatch = value ? 1 : 0;
   else if (std::strcmp(name, "kernel_mode") == 0) {
-    if (value != 0 && value != 1) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "kernel_mode must be 0 or 1");
+    if (value < 0 || value > 2) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "kernel_mode must be 0, 1 or 2");
     ctx->opt_kernel_mode = value;
   } else if (std::strcmp(name, "block_threads") == 0) {
     if (value != 64 && value != 128 && value != 256) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "block_threads must be 64, 128 or 256");
     ctx->opt_block_threads = value;
+  } else if (std::strcmp(name, "refill_min") == 0) {
+    if (value < 1 || value > 64) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "refill_min must be in [1, 64]");
+    ctx->opt_refill_min = value;
+  } else if (std::strcmp(name, "waves_per_cu") == 0) {
+    if (value < 1 || value > 32) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "waves_per_cu must be in [1, 32]");
+    ctx->opt_waves_per_cu = value;
   } else if (std::strcmp(name, "xcd_run") == 0) {
     if (value < 1 || value > 4096) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "xcd_run must be in [1, 4096]");
     ctx->opt_xcd_run = value;
@@ -672,12 +701,15 @@ int urt_get_counters(urt_context* ctx, urt_counters* out) {
   URT_HIP(ctx, hipSetDevice(ctx->device));
   URT_HIP(ctx, hipStreamSynchronize(ctx->stream));
   resolve_timing(ctx);
-  DevCounters dc;
-  URT_HIP(ctx, hipMemcpy(&dc, ctx->d_counters, sizeof dc, hipMemcpyDeviceToHost));
+  std::vector<DevCounters> shards(kCounterShards);
+  URT_HIP(ctx, hipMemcpy(shards.data(), ctx->d_counters, sizeof(DevCounters) * kCounterShards, hipMemcpyDeviceToHost));
   std::memset(out, 0, sizeof *out);
-  out->rays = dc.rays; out->tlas_nodes = dc.tlas_nodes; out->blas_nodes = dc.blas_nodes; out->tri_tests = dc.tri_tests;
-  out->sphere_tests = dc.sphere_tests; out->hit_tri = dc.hit_tri; out->hit_sphere = dc.hit_sphere;
-  out->hit_ground = dc.hit_ground; out->hit_sky = dc.hit_sky; out->pixels = dc.pixels;
+  for (const DevCounters& dc : shards) {
+    out->rays += dc.rays; out->tlas_nodes += dc.tlas_nodes; out->blas_nodes += dc.blas_nodes; out->tri_tests += dc.tri_tests;
+    out->sphere_tests += dc.sphere_tests; out->hit_tri += dc.hit_tri; out->hit_sphere += dc.hit_sphere;
+    out->hit_ground += dc.hit_ground; out->hit_sky += dc.hit_sky;
+  }
+  out->pixels = ctx->pixels_dispatched;
   out->dispatches = ctx->dispatches;
   out->trace_ms = ctx->trace_ms;
   return URT_OK;
@@ -688,8 +720,9 @@ int urt_reset_counters(urt_context* ctx) {
   URT_HIP(ctx, hipSetDevice(ctx->device));
   URT_HIP(ctx, hipStreamSynchronize(ctx->stream));
   resolve_timing(ctx);
-  URT_HIP(ctx, hipMemset(ctx->d_counters, 0, sizeof(DevCounters)));
+  URT_HIP(ctx, hipMemset(ctx->d_counters, 0, sizeof(DevCounters) * kCounterShards));
   ctx->dispatches = 0;
+  ctx->pixels_dispatched = 0;
   ctx->trace_ms = 0;
   return URT_OK;
 }

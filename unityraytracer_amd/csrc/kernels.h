@@ -10,6 +10,9 @@ hipError_t launch_mega(const DevScene& S, const FrameParams& P, float4* result, 
 // mode 1: generate + one launch per bounce over compacted path queues
 hipError_t launch_wavefront(const DevScene& S, const FrameParams& P, const PathQueues& Q, float4* result, DevCounters* ctr,
                             bool count, hipStream_t st);
+// mode 2: persistent waves with path regeneration (one launch per dispatch)
+hipError_t launch_persist(const DevScene& S, const FrameParams& P, float4* result, DevCounters* ctr, unsigned int* next,
+                          int n_blocks, bool count, hipStream_t st);
 // AdditionShader blend (AS:9,39-41)
 hipError_t launch_blit_add(const float4* src, float4* dst, size_t n_pixels, float sample, hipStream_t st);
 // strips <-> dense buffer

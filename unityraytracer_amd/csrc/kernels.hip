@@ -356,16 +356,17 @@ __device__ __forceinline__ unsigned int wave_sum(unsigned int v) {
 
 template <bool COUNT>
 __device__ __forceinline__ void flush_counters(const LocalCounters& lc, DevCounters* ctr) {
-  // wave-reduce then one atomic per wave and counter (diagnostic path; `rays`/`pixels` always)
-  unsigned int r = wave_sum(lc.rays), p = wave_sum(lc.pixels);
+  // wave-reduce, then one atomic per wave and counter into one of kCounterShards slots: tens of
+  // thousands of same-address atomics serialise at ~88/us on this chip, sharded ones do not.
+  ctr += (blockIdx.x & (kCounterShards - 1));
+  unsigned int r = wave_sum(lc.rays);
   unsigned int tn = 0, bn = 0, tt = 0, st = 0, ht = 0, hs = 0, hg = 0, hk = 0;
   if (COUNT) {
     tn = wave_sum(lc.tlas_nodes); bn = wave_sum(lc.blas_nodes); tt = wave_sum(lc.tri_tests); st = wave_sum(lc.sphere_tests);
     ht = wave_sum(lc.hit_tri); hs = wave_sum(lc.hit_sphere); hg = wave_sum(lc.hit_ground); hk = wave_sum(lc.hit_sky);
   }
-  if ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) {
+  if ((threadIdx.x & 63) == 0) {
     if (r) atomicAdd(&ctr->rays, (unsigned long long)r);
-    if (p) atomicAdd(&ctr->pixels, (unsigned long long)p);
     if (COUNT) {
       if (tn) atomicAdd(&ctr->tlas_nodes, (unsigned long long)tn);
       if (bn) atomicAdd(&ctr->blas_nodes, (unsigned long long)bn);
@@ -412,7 +413,79 @@ __global__ __launch_bounds__(256) void k_mega(DevScene S, FrameParams P, float4*
     }
     float n = (float)P.num_rays;
     result[(size_t)y * P.width + x] = make_float4(avg.x / n, avg.y / n, avg.z / n, 1.0f);
-    lc.pixels++;
+  }
+  flush_counters<COUNT>(lc, ctr);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// mode 2 (default): persistent waves with path regeneration.
+// A fixed grid of waves stays resident for the whole frame.  Every lane owns one path at a time; when
+// enough lanes of a wave have finished their pixel (sky hit, energy gone, bounce limit) the wave
+// ballots the dead lanes, takes that many new pixels from the frame's work counter with ONE atomic
+// (prefix popcount gives each dead lane its slot) and starts their camera rays — so the 64 lanes stay
+// busy through all bounces without per-bounce launches or path state round-trips through HBM.
+// Pixels are handed out in tile order (64 consecutive slots = one 8x8 tile), so refills stay coherent.
+// Per-pixel arithmetic is exactly CSMain's (RS:431-469); only the lane a pixel runs on changes.
+// ---------------------------------------------------------------------------------------------------
+template <bool COUNT>
+__global__ __launch_bounds__(256) void k_persist(DevScene S, FrameParams P, float4* __restrict__ result, DevCounters* ctr,
+                                                 unsigned int* __restrict__ next) {
+  int *tl, *bl;
+  lane_stacks(P, tl, bl);
+  LocalCounters lc;
+  const int lane = threadIdx.x & 63;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  const unsigned int total = (unsigned int)(P.tiles_x * P.n_strips) * 64u;
+  bool alive = false, exhausted = false;
+  int x = 0, y = 0, ray_i = 0, k = 0;
+  float px = 0, py = 0, seed = 0;
+  v3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), energy = mk3(0, 0, 0), res = mk3(0, 0, 0), avg = mk3(0, 0, 0);
+  for (;;) {
+    unsigned long long dead = __ballot(!alive);
+    int ndead = __popcll(dead);
+    if (!exhausted && ndead >= P.refill_min) {
+      unsigned int base = 0;
+      if (lane == 0) base = atomicAdd(next, (unsigned int)ndead);
+      base = __shfl(base, 0, 64);
+      if (base + (unsigned int)ndead >= total) exhausted = true;
+      if (!alive) {
+        unsigned int idx = base + (unsigned int)__popcll(dead & lt_mask);
+        if (idx < total) {
+          int tile = (int)(idx >> 6), l = (int)(idx & 63u);
+          int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
+          x = tx * 8 + (l & 7);
+          y = (P.first_group_row + ty * P.row_stride) * 8 + (l >> 3);
+          if (x < P.region_w && y < P.region_h) {
+            alive = true;
+            px = (float)x; py = (float)y;
+            seed = P.seed; ray_i = 0; k = 0;
+            avg = mk3(0, 0, 0); res = mk3(0, 0, 0); energy = mk3(1, 1, 1);
+            camera_ray(P, x, y, seed, o, d);
+          }
+        }
+      }
+    }
+    if (__ballot(alive) == 0) {
+      if (exhausted) break;
+      continue;                       // every fetched slot fell outside the region: fetch again
+    }
+    if (alive) {
+      HitRec h = trace<COUNT>(S, o, d, tl, bl, lc);
+      bool cont = shade<COUNT>(S, h, o, d, energy, res, seed, px, py, lc);
+      k++;
+      if (!cont || k >= P.num_bounces) {            // RS:453,457-460
+        avg = avg + res;                             // RS:464
+        ray_i++;
+        if (ray_i < P.num_rays) {                    // RS:444: next ray of this pixel, _Seed carries over
+          res = mk3(0, 0, 0); energy = mk3(1, 1, 1); k = 0;
+          camera_ray(P, x, y, seed, o, d);
+        } else {
+          float n = (float)P.num_rays;
+          result[(size_t)y * P.width + x] = make_float4(avg.x / n, avg.y / n, avg.z / n, 1.0f);   // RS:468
+          alive = false;
+        }
+      }
+    }
   }
   flush_counters<COUNT>(lc, ctr);
 }
@@ -465,10 +538,6 @@ __global__ __launch_bounds__(256) void k_generate(FrameParams P, PathQueues Q, c
     Q.s[0][1][slot] = make_float4(d.x, d.y, d.z, as_float((y << 16) | x));
     Q.s[0][2][slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
     Q.s[0][3][slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-  }
-  if (ray_index == 0) {
-    unsigned int p = wave_sum(ok ? 1u : 0u);
-    if ((threadIdx.x & 63) == 0 && p) atomicAdd(&ctr->pixels, (unsigned long long)p);
   }
 }
 
@@ -585,6 +654,17 @@ hipError_t launch_wavefront(const DevScene& S, const FrameParams& P, const PathQ
       else hipLaunchKernelGGL(k_bounce<false>, dim3(nbb), dim3(bt), lds, st, S, P, Q, result, i, k, ctr);
     }
   }
+  return hipGetLastError();
+}
+
+hipError_t launch_persist(const DevScene& S, const FrameParams& P, float4* result, DevCounters* ctr, unsigned int* next,
+                          int n_blocks, bool count, hipStream_t st) {
+  if (n_blocks <= 0) return hipSuccess;
+  hipError_t e = hipMemsetAsync(next, 0, sizeof(unsigned int), st);
+  if (e != hipSuccess) return e;
+  size_t lds = stack_lds_bytes(P);
+  if (count) hipLaunchKernelGGL(k_persist<true>, dim3(n_blocks), dim3(P.block_threads), lds, st, S, P, result, ctr, next);
+  else hipLaunchKernelGGL(k_persist<false>, dim3(n_blocks), dim3(P.block_threads), lds, st, S, P, result, ctr, next);
   return hipGetLastError();
 }
 
