@@ -45,6 +45,18 @@ def algorithmic_bytes(c: dict) -> int:
     return sum(BYTES[k] * int(c[k]) for k in BYTES)
 
 
+def usable_cores() -> int:
+    """Host cores this process may really use: affinity mask, capped by the cgroup CPU quota (cpu.max)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -170,7 +182,7 @@ def main():
             if len(scene.mesh_objects):
                 nodes, tri, root, _, _ = debug_build_blas(scene.mesh_objects, scene.vertices, scene.indices)
                 o.set_blas(nodes, tri, root)
-            cores = min(pyoracle.hardware_threads(), len(os.sched_getaffinity(0)))
+            cores = min(pyoracle.hardware_threads(), usable_cores())
             tc = time.perf_counter()
             _, oc = o.render(mode=1, threads=cores, counters=True)
             dt = time.perf_counter() - tc
