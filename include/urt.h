@@ -139,7 +139,7 @@ typedef struct urt_counters {
   uint64_t pixels;        /* pixels written (16 B each) */
   uint64_t dispatches;    /* urt_shader_dispatch* calls since reset */
   float trace_ms;         /* GPU time of the trace kernels of those dispatches (HIP events) */
-  float reserved;
+  uint32_t watchdog_trips; /* waves that hit a persistent kernel's iteration cap: always 0 unless there is a bug */
 } urt_counters;
 /* Options: "count_stats" (0/1: per-dispatch traversal counters, slower build of the kernel),
  *          "time_dispatch" (0/1: bracket each dispatch with HIP events, read by urt_get_counters),

@@ -246,6 +246,16 @@ URT_HD v3 mul_m4(const float* m, float x, float y, float z, float w) {
   return r;
 }
 
+// 1/d for the triangle-BVH slab test (not a reference function: the reference has no triangle BVH).
+// |d| < 1e-18 (in particular d == +-0: a diffuse bounce whose rand() returned exactly 0 leaves exactly
+// tangent to the surface) is treated as +-1e-18, so the fma form t = b * (1/d) - o * (1/d) never becomes
+// inf - inf = NaN, which would switch that axis off and walk a whole slab of the mesh.
+URT_HD float blas_rcp(float d) {
+  float r = 1.0f / d;
+  if (f_abs(d) < 1e-18f) r = (f_bits(d) >> 31) ? -1e18f : 1e18f;
+  return r;
+}
+
 // ---------------------------------------------------------------------------------------------
 // rand()  (RS:77-81, A.1).  State: pixel (float2 of absolute pixel coordinates) + running seed.
 // ---------------------------------------------------------------------------------------------

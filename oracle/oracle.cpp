@@ -62,6 +62,8 @@ struct OracleScene {
 struct OracleCounters {
   uint64_t rays, tlas_nodes, blas_nodes, tri_tests, sphere_tests;
   uint64_t hit_tri, hit_sphere, hit_ground, hit_sky, pixels;
+  uint64_t max_ray_steps;       // diagnostics: most BVH nodes + triangle tests any single Trace() needed
+  uint64_t rays_over_256_steps; // diagnostics: Trace() calls that needed more than 256 of them
 };
 
 }  // extern "C"
@@ -241,7 +243,7 @@ struct Tracer {
     if (root == 0x7fffffff) return;
     v3 o = ray.origin, d = ray.direction;
     float pad = f_max(f_max(f_abs(o.x), f_abs(o.y)), f_abs(o.z)) * 1.52587890625e-5f;
-    v3 idir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    v3 idir = mk3(blas_rcp(d.x), blas_rcp(d.y), blas_rcp(d.z));
     v3 nop = mk3(-((o.x + pad) * idir.x), -((o.y + pad) * idir.y), -((o.z + pad) * idir.z));
     v3 nom = mk3(-((o.x - pad) * idir.x), -((o.y - pad) * idir.y), -((o.z - pad) * idir.z));
     int32_t stack[128];
@@ -360,10 +362,14 @@ struct Tracer {
   // RS:364-383
   RayHit Trace(const Ray& ray) {
     C.rays++;
+    uint64_t steps0 = C.blas_nodes + C.tri_tests;
     RayHit bestHit = CreateRayHit();
     IntersectGroundPlane(ray, bestHit);
     if (S.n_mesh_objects > 0) IntersectMeshBVH(ray, bestHit);
     if (S.n_spheres > 0) IntersectSphereBVH(ray, bestHit);
+    uint64_t steps = C.blas_nodes + C.tri_tests - steps0;
+    if (steps > C.max_ray_steps) C.max_ray_steps = steps;
+    if (steps > 256) C.rays_over_256_steps++;
     return bestHit;
   }
 
@@ -460,6 +466,8 @@ static void add_counters(OracleCounters& a, const OracleCounters& b) {
   a.rays += b.rays; a.tlas_nodes += b.tlas_nodes; a.blas_nodes += b.blas_nodes; a.tri_tests += b.tri_tests;
   a.sphere_tests += b.sphere_tests; a.hit_tri += b.hit_tri; a.hit_sphere += b.hit_sphere;
   a.hit_ground += b.hit_ground; a.hit_sky += b.hit_sky; a.pixels += b.pixels;
+  if (b.max_ray_steps > a.max_ray_steps) a.max_ray_steps = b.max_ray_steps;
+  a.rays_over_256_steps += b.rays_over_256_steps;
 }
 
 }  // namespace

@@ -38,7 +38,7 @@ class OracleScene(C.Structure):
 
 class OracleCounters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("rays", "tlas_nodes", "blas_nodes", "tri_tests", "sphere_tests", "hit_tri", "hit_sphere",
-                                          "hit_ground", "hit_sky", "pixels")]
+                                          "hit_ground", "hit_sky", "pixels", "max_ray_steps", "rays_over_256_steps")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

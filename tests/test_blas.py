@@ -109,3 +109,40 @@ def test_equal_t_tie_goes_to_lowest_index_slot(built_library):
     assert np.array_equal(brute.view(np.uint32), culled.view(np.uint32))
     centre = brute[16, 16, :3].tolist()
     assert centre in ([1.0, 0.0, 0.0], [0.0, 1.0, 0.0])      # whichever object the heap visits first wins, identically in both modes
+
+
+def test_axis_parallel_rays_match_brute_force(built_library):
+    """Rays with direction components that are EXACTLY zero (a diffuse bounce whose rand() returned 0 leaves exactly
+    tangent to the surface, e.g. d.y == 0 off the ground plane).  1/0 = inf must not turn the slab test into
+    inf - inf = NaN (which both mis-culls and walks a whole slab of the mesh): blas_rcp() in urt_math.h."""
+    sc = scenes.config3(64, 36, slices=48, stacks=37, sky=scenes.make_sky(64, 32))
+    o = pyoracle.Oracle(sc)
+    nodes, tri, root, _, _ = debug_build_blas(sc.mesh_objects, sc.vertices, sc.indices)
+    rng = np.random.default_rng(5)
+    rays = []
+    for _ in range(300):
+        p = np.array([rng.uniform(-3, 3), rng.uniform(0.001, 5), rng.uniform(-7, -1)])
+        ax = rng.integers(0, 3)
+        d = rng.normal(size=3)
+        d[ax] = 0.0                                   # one exact zero
+        if rng.random() < 0.3:
+            d[(ax + 1) % 3] = 0.0                     # two exact zeros: axis-aligned
+        d /= np.linalg.norm(d)
+        rays.append((p - 6 * d, d))
+    rays.append((np.array([0.9, 0.001, -8.2]), np.array([-0.104122, 0.0, 0.994565])))     # a measured pathological ray
+    o.set_blas(nodes, tri, root)
+    worst = 0
+    for p, d in rays:
+        a = o.trace(p, d, mode=0)
+        c0 = pyoracle.OracleCounters()
+        b = o.trace(p, d, mode=1)
+        assert a["kind"] == b["kind"] and (a["distance"] == b["distance"] or (np.isinf(a["distance"]) and np.isinf(b["distance"])))
+        assert np.array_equal(a["normal"], b["normal"], equal_nan=True)
+    # and the traversal stays local: a horizontal ray skimming the ground under the mesh visits few nodes
+    sc2 = scenes.config3(32, 18, sky=scenes.make_sky(64, 32))
+    o2 = pyoracle.Oracle(sc2)
+    n2, t2, r2, _, _ = debug_build_blas(sc2.mesh_objects, sc2.vertices, sc2.indices)
+    o2.set_blas(n2, t2, r2)
+    sc2.num_bounces = 8
+    _, c = o2.render(mode=1, threads=8, counters=True)
+    assert c["max_ray_steps"] < 600

@@ -43,7 +43,7 @@ def oracle_for(scene, use_product_blas=True):
     return o
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
 def test_mixed_scene_bit_exact(gpu_ctx, mode):
     sc = scenes.mixed_test_scene(200, 120)           # ragged: not a multiple of 8
     o = oracle_for(sc)
@@ -54,7 +54,7 @@ def test_mixed_scene_bit_exact(gpu_ctx, mode):
         assert gc[k] == oc[k], (k, gc[k], oc[k])
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
 def test_config1_spheres_bit_exact(gpu_ctx, mode):
     sc = scenes.config1()
     ref = pyoracle.Oracle(sc).render(mode=0, threads=8)
@@ -66,7 +66,7 @@ def test_config3_mesh_quarter_res_bit_exact(gpu_ctx):
     sc = scenes.config3(480, 270, sky=scenes.make_sky(512, 256))
     o = oracle_for(sc)
     ref = o.render(mode=1, threads=8)
-    for mode in (2, 1):
+    for mode in (3, 2, 1):
         gpu, _, _ = render_gpu(gpu_ctx, sc, mode)
         assert_same(gpu, ref, f"C3 480x270 mode {mode}")
     # and the literal brute-force loop of RS:243 on a crop through the mesh
@@ -84,7 +84,7 @@ def test_multi_ray_multi_frame_accumulation(gpu_ctx):
         ox, oy, seed = scenes.frame_uniforms(f)
         o.set_frame((ox, oy), seed)
         conv_ref = pyoracle.accumulate(o.render(mode=1, threads=8), conv_ref, f)
-    for mode in (0, 1, 2):
+    for mode in (0, 1, 2, 3):
         _, conv, _ = render_gpu(gpu_ctx, sc, mode, frames=3)
         assert_same(conv, conv_ref, f"3-frame running mean, mode {mode}")
 

@@ -27,10 +27,10 @@ ABI_SYMBOLS = [
 
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("rays", "tlas_nodes", "blas_nodes", "tri_tests", "sphere_tests", "hit_tri", "hit_sphere",
-                                          "hit_ground", "hit_sky", "pixels", "dispatches")] + [("trace_ms", C.c_float), ("reserved", C.c_float)]
+                                          "hit_ground", "hit_sky", "pixels", "dispatches")] + [("trace_ms", C.c_float), ("watchdog_trips", C.c_uint32)]
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
+        return {n: getattr(self, n) for n, _ in self._fields_}
 
 
 class UrtError(RuntimeError):

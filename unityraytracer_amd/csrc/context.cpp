@@ -86,7 +86,7 @@ struct urt_context {
   float trace_ms = 0;
 
   int opt_count_stats = 0, opt_time_dispatch = 0, opt_kernel_mode = 2;
-  int opt_block_threads = 64, opt_xcd_run = 1, opt_refill_min = 16, opt_waves_per_cu = 16;
+  int opt_block_threads = 64, opt_xcd_run = 1, opt_refill_min = 16, opt_waves_per_cu = 16, opt_blas_min = 40, opt_blas_exit = 12;
 };
 
 namespace {
@@ -309,7 +309,7 @@ int do_dispatch(urt_context* ctx, int kernel, int gx, int gy, int gz, int first_
   P.first_group_row = first_row; P.row_stride = row_stride;
   P.n_strips = first_row < group_rows ? (group_rows - first_row + row_stride - 1) / row_stride : 0;
   P.tlas_stack = ctx->tlas_stack; P.blas_stack = ctx->blas_stack;
-  P.block_threads = ctx->opt_block_threads; P.xcd_run = ctx->opt_xcd_run; P.refill_min = ctx->opt_refill_min;
+  P.block_threads = ctx->opt_block_threads; P.xcd_run = ctx->opt_xcd_run; P.refill_min = ctx->opt_refill_min; P.blas_min = ctx->opt_blas_min; P.blas_exit = ctx->opt_blas_exit;
   if (P.n_strips == 0 || P.tiles_x == 0) return URT_OK;
 
   // region pixels this dispatch writes (threads outside Result write nothing, RS:468)
@@ -337,11 +337,13 @@ int do_dispatch(urt_context* ctx, int kernel, int gx, int gy, int gz, int first_
   bool count = ctx->opt_count_stats != 0;
   hipError_t le;
   if (mode == 1) le = launch_wavefront(S, P, ctx->q, res->dev, ctx->d_counters, count, ctx->stream);
-  else if (mode == 2) {
+  else if (mode == 2 || mode == 3) {
     int waves_per_block = P.block_threads / 64;
     long want = ((long)P.tiles_x * P.n_strips + waves_per_block - 1) / waves_per_block;
     long resident = (long)ctx->n_cus * ctx->opt_waves_per_cu / waves_per_block;
-    le = launch_persist(S, P, res->dev, ctx->d_counters, ctx->d_next, (int)std::max(1L, std::min(want, resident)), count, ctx->stream);
+    int nb = (int)std::max(1L, std::min(want, resident));
+    le = mode == 2 ? launch_persist(S, P, res->dev, ctx->d_counters, ctx->d_next, nb, count, ctx->stream)
+                   : launch_sched(S, P, res->dev, ctx->d_counters, ctx->d_next, nb, count, ctx->stream);
   } else le = launch_mega(S, P, res->dev, ctx->d_counters, count, ctx->stream);
   if (ctx->opt_time_dispatch) {
     (void)hipEventRecord(e1, ctx->stream);
@@ -383,7 +385,7 @@ int urt_context_create(int device, urt_context** out_ctx) {
   ctx->stream = ctx->own_stream;
   e = hipMalloc((void**)&ctx->d_counters, sizeof(DevCounters) * kCounterShards);
   if (e == hipSuccess) e = hipMemset(ctx->d_counters, 0, sizeof(DevCounters) * kCounterShards);
-  if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_next, sizeof(unsigned int));
+  if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_next, 64 + 65536 * 4 * sizeof(unsigned long long));   // [0] work counter; the rest: diagnostic stamps (URT_STAMPS builds)
   if (e == hipSuccess) { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n > 0) ctx->n_cus = n; }
   if (e != hipSuccess) { (void)hipStreamDestroy(ctx->own_stream); delete ctx; return fail(nullptr, URT_ERR_HIP, std::string("counter allocation: ") + hipGetErrorString(e)); }
   *out_ctx = ctx;
@@ -677,11 +679,17 @@ int urt_set_option(urt_context* ctx, const char* name, int value) {
   if (std::strcmp(name, "count_stats") == 0) ctx->opt_count_stats = value ? 1 : 0;
   else if (std::strcmp(name, "time_dispatch") == 0) ctx->opt_time_dispatch = value ? 1 : 0;
   else if (std::strcmp(name, "kernel_mode") == 0) {
-    if (value < 0 || value > 2) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "kernel_mode must be 0, 1 or 2");
+    if (value < 0 || value > 3) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "kernel_mode must be 0..3");
     ctx->opt_kernel_mode = value;
   } else if (std::strcmp(name, "block_threads") == 0) {
     if (value != 64 && value != 128 && value != 256) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "block_threads must be 64, 128 or 256");
     ctx->opt_block_threads = value;
+  } else if (std::strcmp(name, "blas_min") == 0) {
+    if (value < 1 || value > 64) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "blas_min must be in [1, 64]");
+    ctx->opt_blas_min = value;
+  } else if (std::strcmp(name, "blas_exit") == 0) {
+    if (value < 1 || value > 64) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "blas_exit must be in [1, 64]");
+    ctx->opt_blas_exit = value;
   } else if (std::strcmp(name, "refill_min") == 0) {
     if (value < 1 || value > 64) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "refill_min must be in [1, 64]");
     ctx->opt_refill_min = value;
@@ -708,6 +716,7 @@ int urt_get_counters(urt_context* ctx, urt_counters* out) {
     out->rays += dc.rays; out->tlas_nodes += dc.tlas_nodes; out->blas_nodes += dc.blas_nodes; out->tri_tests += dc.tri_tests;
     out->sphere_tests += dc.sphere_tests; out->hit_tri += dc.hit_tri; out->hit_sphere += dc.hit_sphere;
     out->hit_ground += dc.hit_ground; out->hit_sky += dc.hit_sky;
+    out->watchdog_trips += (uint32_t)dc.watchdog;
   }
   out->pixels = ctx->pixels_dispatched;
   out->dispatches = ctx->dispatches;
@@ -726,6 +735,14 @@ int urt_reset_counters(urt_context* ctx) {
   ctx->trace_ms = 0;
   return URT_OK;
 }
+
+#ifdef URT_STAMPS
+/* diagnostic builds only: per-wave (start, pool-exhausted, end, iters<<32|fetches) of the last persistent launch */
+__attribute__((visibility("default"))) int urt_debug_read_stamps(urt_context* ctx, unsigned long long* out, int n_waves) {
+  (void)hipStreamSynchronize(ctx->stream);
+  return (int)hipMemcpy(out, (char*)ctx->d_next + 64, (size_t)n_waves * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+}
+#endif
 
 /* ---- introspection ---- */
 int urt_debug_build_blas(const void* mesh_objects, int n_meshes, const float* vertices, int n_vertices, const int32_t* indices,

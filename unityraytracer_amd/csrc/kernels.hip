@@ -85,7 +85,7 @@ __device__ __forceinline__ void intersect_mesh(const DevScene& S, int32_t root, 
   if (root == kEmptyMeshRoot) return;
   // per-ray slab constants: boxes are widened by pad = 2^-16 * max|origin| on top of the build-time pad
   float pad = f_max(f_max(f_abs(o.x), f_abs(o.y)), f_abs(o.z)) * 1.52587890625e-5f;
-  v3 idir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  v3 idir = mk3(blas_rcp(d.x), blas_rcp(d.y), blas_rcp(d.z));
   v3 nop = mk3(-((o.x + pad) * idir.x), -((o.y + pad) * idir.y), -((o.z + pad) * idir.z));
   v3 nom = mk3(-((o.x - pad) * idir.x), -((o.y - pad) * idir.y), -((o.z - pad) * idir.z));
   int best_i = -1;          // index slot of a hit made in THIS call (enables the equal-t tie rule)
@@ -437,6 +437,9 @@ __global__ __launch_bounds__(256) void k_persist(DevScene S, FrameParams P, floa
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   const unsigned int total = (unsigned int)(P.tiles_x * P.n_strips) * 64u;
   bool alive = false, exhausted = false;
+#ifdef URT_STAMPS
+  unsigned long long t_start = wall_clock64(), t_exh = 0; unsigned int n_iter = 0, n_fetch = 0;
+#endif
   int x = 0, y = 0, ray_i = 0, k = 0;
   float px = 0, py = 0, seed = 0;
   v3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), energy = mk3(0, 0, 0), res = mk3(0, 0, 0), avg = mk3(0, 0, 0);
@@ -448,6 +451,9 @@ __global__ __launch_bounds__(256) void k_persist(DevScene S, FrameParams P, floa
       if (lane == 0) base = atomicAdd(next, (unsigned int)ndead);
       base = __shfl(base, 0, 64);
       if (base + (unsigned int)ndead >= total) exhausted = true;
+#ifdef URT_STAMPS
+      n_fetch++; if (exhausted && !t_exh) t_exh = wall_clock64();
+#endif
       if (!alive) {
         unsigned int idx = base + (unsigned int)__popcll(dead & lt_mask);
         if (idx < total) {
@@ -469,6 +475,9 @@ __global__ __launch_bounds__(256) void k_persist(DevScene S, FrameParams P, floa
       if (exhausted) break;
       continue;                       // every fetched slot fell outside the region: fetch again
     }
+#ifdef URT_STAMPS
+    n_iter++;
+#endif
     if (alive) {
       HitRec h = trace<COUNT>(S, o, d, tl, bl, lc);
       bool cont = shade<COUNT>(S, h, o, d, energy, res, seed, px, py, lc);
@@ -487,6 +496,276 @@ __global__ __launch_bounds__(256) void k_persist(DevScene S, FrameParams P, floa
       }
     }
   }
+#ifdef URT_STAMPS
+  if (lane == 0) {
+    unsigned long long* st = (unsigned long long*)(next + 16);
+    size_t w = ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 4;
+    st[w] = t_start; st[w + 1] = t_exh; st[w + 2] = wall_clock64(); st[w + 3] = ((unsigned long long)n_iter << 32) | n_fetch;
+  }
+#endif
+  flush_counters<COUNT>(lc, ctr);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// mode 3: persistent waves, lanes SCHEDULED BY PHASE inside the wave.
+// Measured on mode 2 (profiles/README.md): after the first bounce only a minority of a wave's lanes needs
+// the triangle-BVH loop and the rest idle through it (18 % VALU lane utilisation).  Here every lane carries
+// a small state machine
+//     DEAD -> FRONT (ground plane + object-level heap walk) -> BLAS (triangle BVH of one MeshObject)
+//          -> RESUME (rest of the heap walk, spheres) -> SHADE -> FRONT (next bounce / ray) | DEAD
+// and each trip round the wave loop the 64 lanes vote (ballot) on ONE phase to run.  Cheap phases (SHADE,
+// FRONT, refill) run until at least `blas_min` lanes are parked in BLAS, then the traversal loop runs with
+// that many lanes; it hands control back when fewer than `blas_exit` lanes are still traversing (their
+// stack lives in LDS and the node cursor in registers, so they resume later).  Per-pixel arithmetic and the
+// order of its operations are exactly those of modes 0-2 (same device functions) — only WHEN a lane
+// executes them changes, so pixels are bit-identical.
+// ---------------------------------------------------------------------------------------------------
+enum : int { ST_DEAD = 0, ST_FRONT = 1, ST_RESUME = 2, ST_BLAS = 3, ST_SHADE = 4 };
+static constexpr int32_t kBlasDone = (int32_t)0x80000000;   // never a valid leaf code (~0x7fffffff)
+static constexpr unsigned int kWatchdogIters = 1u << 24;    // scheduler trips per wave (a frame needs ~1e3-1e5)
+static constexpr unsigned int kWatchdogSteps = 1u << 24;    // traversal steps per scheduled BLAS phase
+
+template <bool COUNT>
+__global__ __launch_bounds__(256) void k_sched(DevScene S, FrameParams P, float4* __restrict__ result, DevCounters* ctr,
+                                               unsigned int* __restrict__ next) {
+  int *tl, *bl;
+  lane_stacks(P, tl, bl);
+  LocalCounters lc;
+  const int lane = threadIdx.x & 63;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  const unsigned int total = (unsigned int)(P.tiles_x * P.n_strips) * 64u;
+  bool exhausted = false;
+  int st = ST_DEAD;
+  // path state
+  int x = 0, y = 0, ray_i = 0, k = 0;
+  float seed = 0;
+  v3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), energy = mk3(0, 0, 0), res = mk3(0, 0, 0), avg = mk3(0, 0, 0);
+  // trace state (one Trace() in flight per lane)
+  HitRec best; best.t = URT_INF; best.kind = 0; best.id = 0; best.u = 0; best.v = 0;
+  int check = 0; bool seen = false;              // object-level heap walk (RS:294-326)
+  int32_t cur = kBlasDone; int sp = 0, best_i = -1;   // triangle-BVH cursor of the current MeshObject
+  unsigned int wave_iters = 0;
+  bool watchdog = false;
+
+  for (;;) {
+    if (watchdog) break;
+    unsigned long long mD = __ballot(st == ST_DEAD);
+    int nD = __popcll(mD);
+    // ---- refill dead lanes from the frame's work counter (one atomic per refill) ----
+    if (!exhausted && nD >= P.refill_min) {
+      unsigned int base = 0;
+      if (lane == 0) base = atomicAdd(next, (unsigned int)nD);
+      base = __shfl(base, 0, 64);
+      if (base + (unsigned int)nD >= total) exhausted = true;
+      if (st == ST_DEAD) {
+        unsigned int idx = base + (unsigned int)__popcll(mD & lt_mask);
+        if (idx < total) {
+          int tile = (int)(idx >> 6), l = (int)(idx & 63u);
+          int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
+          x = tx * 8 + (l & 7);
+          y = (P.first_group_row + ty * P.row_stride) * 8 + (l >> 3);
+          if (x < P.region_w && y < P.region_h) {
+            st = ST_FRONT;
+            seed = P.seed; ray_i = 0; k = 0;
+            avg = mk3(0, 0, 0); res = mk3(0, 0, 0); energy = mk3(1, 1, 1);
+            camera_ray(P, x, y, seed, o, d);
+          }
+        }
+      }
+    }
+    int nB = __popcll(__ballot(st == ST_BLAS));
+    int nS = __popcll(__ballot(st == ST_SHADE));
+    int nF = __popcll(__ballot(st == ST_FRONT || st == ST_RESUME));
+    nD = __popcll(__ballot(st == ST_DEAD));
+    bool can_refill = !exhausted && nD >= P.refill_min;
+    if (++wave_iters > kWatchdogIters) { watchdog = true; break; }   // an exit every wave reaches, whatever the data
+    int phase;
+    int exit_below = 1;              // traversal runs to completion unless other lanes can make progress meanwhile
+    if (nB >= P.blas_min) { phase = ST_BLAS; if (nS + nF > 0 || can_refill) exit_below = P.blas_exit; }
+    else if (nS > 0) phase = ST_SHADE;
+    else if (nF > 0) phase = ST_FRONT;
+    else if (can_refill) continue;
+    else if (nB > 0) phase = ST_BLAS;
+    else if (!exhausted) { if (nD > 0 && nD < P.refill_min) { /* force a refill below the threshold */
+        unsigned long long m2 = __ballot(st == ST_DEAD);
+        unsigned int base = 0;
+        if (lane == 0) base = atomicAdd(next, (unsigned int)nD);
+        base = __shfl(base, 0, 64);
+        if (base + (unsigned int)nD >= total) exhausted = true;
+        if (st == ST_DEAD) {
+          unsigned int idx = base + (unsigned int)__popcll(m2 & lt_mask);
+          if (idx < total) {
+            int tile = (int)(idx >> 6), l = (int)(idx & 63u);
+            int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
+            x = tx * 8 + (l & 7);
+            y = (P.first_group_row + ty * P.row_stride) * 8 + (l >> 3);
+            if (x < P.region_w && y < P.region_h) {
+              st = ST_FRONT;
+              seed = P.seed; ray_i = 0; k = 0;
+              avg = mk3(0, 0, 0); res = mk3(0, 0, 0); energy = mk3(1, 1, 1);
+              camera_ray(P, x, y, seed, o, d);
+            }
+          }
+        }
+      }
+      continue;
+    } else break;
+
+    if (phase == ST_FRONT) {
+      // ---------------- FRONT / RESUME: Trace() up to the next triangle-BVH visit (RS:364-383) ----------------
+      if (st == ST_FRONT || st == ST_RESUME) {
+        if (st == ST_FRONT) {
+          lc.rays++;
+          best.t = URT_INF; best.kind = 0; best.id = 0; best.u = 0; best.v = 0;
+          float t = -o.y / d.y;                                   // IntersectGroundPlane RS:156-172
+          if (t > 0 && t < best.t) { best.t = t; best.kind = 1; }
+          check = 0; seen = false;
+          if (S.n_meshes > 0) { check = 1; tl[0] = 0; }
+        }
+        v3 rcp = mk3(1.0f / (d.x + kEPSILON), 1.0f / (d.y + kEPSILON), 1.0f / (d.z + kEPSILON));
+        bool need_blas = false;
+        while (check > 0) {                                        // IntersectMeshBVH RS:294-326
+          check--;
+          int bi = tl[check * 64];
+          bool hit = false; int index = -1;
+          if (bi < S.n_mesh_tlas) {
+            if (COUNT) lc.tlas_nodes++;
+            float4 a = S.mesh_tlas[2 * bi], b = S.mesh_tlas[2 * bi + 1];
+            index = as_int(a.w);
+            hit = tlas_slab(a, b, o, rcp);
+          }
+          if (hit) {
+            if (index < 0) { tl[check * 64] = bi * 2 + 1; check++; tl[check * 64] = bi * 2 + 2; check++; }
+            else seen = true;
+          }
+          if (seen && index >= 0 && index < S.n_meshes) {
+            int32_t root = S.mesh_root[index];
+            if (root != kEmptyMeshRoot) { cur = root; sp = 0; best_i = -1; need_blas = true; break; }
+          }
+        }
+        if (need_blas) {
+          st = ST_BLAS;
+        } else {
+          if (S.n_spheres > 0) {                                   // IntersectSphereBVH RS:329-361
+            int c2 = 1; tl[0] = 0; bool seen2 = false;
+            while (c2 > 0) {
+              c2--;
+              int bi = tl[c2 * 64];
+              bool hit = false; int index = -1;
+              if (bi < S.n_sphere_tlas) {
+                if (COUNT) lc.tlas_nodes++;
+                float4 a = S.sphere_tlas[2 * bi], b = S.sphere_tlas[2 * bi + 1];
+                index = as_int(a.w);
+                hit = tlas_slab(a, b, o, rcp);
+              }
+              if (hit) {
+                if (index < 0) { tl[c2 * 64] = bi * 2 + 1; c2++; tl[c2 * 64] = bi * 2 + 2; c2++; }
+                else seen2 = true;
+              }
+              if (seen2 && index >= 0 && index < S.n_spheres) intersect_sphere<COUNT>(S, index, o, d, best, lc);
+            }
+          }
+          st = ST_SHADE;
+        }
+      }
+    } else if (phase == ST_BLAS) {
+      // ---------------- BLAS: triangle BVH of one MeshObject, resumable ----------------
+      bool mine = st == ST_BLAS;
+      float pad = f_max(f_max(f_abs(o.x), f_abs(o.y)), f_abs(o.z)) * 1.52587890625e-5f;
+      v3 idir = mk3(blas_rcp(d.x), blas_rcp(d.y), blas_rcp(d.z));
+      v3 nop = mk3(-((o.x + pad) * idir.x), -((o.y + pad) * idir.y), -((o.z + pad) * idir.z));
+      v3 nom = mk3(-((o.x - pad) * idir.x), -((o.y - pad) * idir.y), -((o.z - pad) * idir.z));
+      bool active = mine && cur != kBlasDone;
+      unsigned int steps = 0;
+      while (__popcll(__ballot(active)) >= exit_below) {
+        if (++steps > kWatchdogSteps) { watchdog = true; break; }
+        if (active) {
+          // descend interior nodes until this lane holds a leaf (or is done)
+          if (cur >= 0) {
+            if (COUNT) lc.blas_nodes++;
+            const float4* n = S.blas_nodes + 4 * (size_t)cur;
+            float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
+            float tb = best.t;
+            float a1x = f_fma(q0.x, idir.x, nop.x), a2x = f_fma(q0.w, idir.x, nom.x);
+            float a1y = f_fma(q0.y, idir.y, nop.y), a2y = f_fma(q1.x, idir.y, nom.y);
+            float a1z = f_fma(q0.z, idir.z, nop.z), a2z = f_fma(q1.y, idir.z, nom.z);
+            float tn0 = f_max(f_max(f_min(a1x, a2x), f_min(a1y, a2y)), f_max(f_min(a1z, a2z), 0.0f));
+            float tf0 = f_min(f_min(f_max(a1x, a2x), f_max(a1y, a2y)), f_min(f_max(a1z, a2z), tb));
+            float b1x = f_fma(q1.z, idir.x, nop.x), b2x = f_fma(q2.y, idir.x, nom.x);
+            float b1y = f_fma(q1.w, idir.y, nop.y), b2y = f_fma(q2.z, idir.y, nom.y);
+            float b1z = f_fma(q2.x, idir.z, nop.z), b2z = f_fma(q2.w, idir.z, nom.z);
+            float tn1 = f_max(f_max(f_min(b1x, b2x), f_min(b1y, b2y)), f_max(f_min(b1z, b2z), 0.0f));
+            float tf1 = f_min(f_min(f_max(b1x, b2x), f_max(b1y, b2y)), f_min(f_max(b1z, b2z), tb));
+            bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
+            int32_t c0 = as_int(q3.x), c1 = as_int(q3.y);
+            if (h0 && h1) {
+              bool swap = tn1 < tn0;
+              bl[sp * 64] = swap ? c0 : c1;
+              sp++;
+              cur = swap ? c1 : c0;
+            } else if (h0) {
+              cur = c0;
+            } else if (h1) {
+              cur = c1;
+            } else if (sp == 0) {
+              cur = kBlasDone;
+            } else {
+              sp--;
+              cur = bl[sp * 64];
+            }
+          } else {
+            uint32_t code = ~(uint32_t)cur;
+            uint32_t first = code >> 3, cnt = (code & 7u) + 1u;
+            for (uint32_t j = 0; j < cnt; j++) {
+              if (COUNT) lc.tri_tests++;
+              const float4* tv = S.tri_verts + 3 * (size_t)(first + j);
+              float4 r0 = tv[0], r1 = tv[1], r2 = tv[2];
+              v3 edge1 = xyz(r1), edge2 = xyz(r2);
+              v3 pvec = cross(d, edge2);
+              float det = dot(edge1, pvec);
+              if (det < kEPSILON) continue;
+              float inv_det = 1.0f / det;
+              v3 tvec = o - xyz(r0);
+              float u = dot(tvec, pvec) * inv_det;
+              if (u < 0.0f || u > 1.0f) continue;
+              v3 qvec = cross(tvec, edge1);
+              float v = dot(d, qvec) * inv_det;
+              if (v < 0.0f || u + v > 1.0f) continue;
+              float t = dot(edge2, qvec) * inv_det;
+              int islot = as_int(r0.w);
+              bool closer = (t > 0 && t < best.t) || (t > 0 && t == best.t && best_i >= 0 && islot < best_i);
+              if (closer) { best.t = t; best.kind = 3; best.id = (int)(first + j); best.u = u; best.v = v; best_i = islot; }
+            }
+            if (sp == 0) cur = kBlasDone;
+            else { sp--; cur = bl[sp * 64]; }
+          }
+          active = cur != kBlasDone;
+        }
+      }
+      if (mine && cur == kBlasDone) st = ST_RESUME;               // back to the heap walk (RS:323-325 continues)
+    } else {
+      // ---------------- SHADE + bookkeeping of CSMain's loops (RS:444-468) ----------------
+      if (st == ST_SHADE) {
+        float px = (float)x, py = (float)y;
+        bool cont = shade<COUNT>(S, best, o, d, energy, res, seed, px, py, lc);
+        k++;
+        st = ST_FRONT;
+        if (!cont || k >= P.num_bounces) {
+          avg = avg + res;
+          ray_i++;
+          if (ray_i < P.num_rays) {
+            res = mk3(0, 0, 0); energy = mk3(1, 1, 1); k = 0;
+            camera_ray(P, x, y, seed, o, d);
+          } else {
+            float n = (float)P.num_rays;
+            result[(size_t)y * P.width + x] = make_float4(avg.x / n, avg.y / n, avg.z / n, 1.0f);
+            st = ST_DEAD;
+          }
+        }
+      }
+    }
+  }
+  if (watchdog && lane == 0) atomicAdd(&ctr->watchdog, 1ull);
   flush_counters<COUNT>(lc, ctr);
 }
 
@@ -665,6 +944,17 @@ hipError_t launch_persist(const DevScene& S, const FrameParams& P, float4* resul
   size_t lds = stack_lds_bytes(P);
   if (count) hipLaunchKernelGGL(k_persist<true>, dim3(n_blocks), dim3(P.block_threads), lds, st, S, P, result, ctr, next);
   else hipLaunchKernelGGL(k_persist<false>, dim3(n_blocks), dim3(P.block_threads), lds, st, S, P, result, ctr, next);
+  return hipGetLastError();
+}
+
+hipError_t launch_sched(const DevScene& S, const FrameParams& P, float4* result, DevCounters* ctr, unsigned int* next,
+                        int n_blocks, bool count, hipStream_t st) {
+  if (n_blocks <= 0) return hipSuccess;
+  hipError_t e = hipMemsetAsync(next, 0, sizeof(unsigned int), st);
+  if (e != hipSuccess) return e;
+  size_t lds = stack_lds_bytes(P);
+  if (count) hipLaunchKernelGGL(k_sched<true>, dim3(n_blocks), dim3(P.block_threads), lds, st, S, P, result, ctr, next);
+  else hipLaunchKernelGGL(k_sched<false>, dim3(n_blocks), dim3(P.block_threads), lds, st, S, P, result, ctr, next);
   return hipGetLastError();
 }
 

@@ -52,13 +52,16 @@ struct FrameParams {
   int blas_stack;           // LDS entries per lane reserved for the triangle-BVH stack
   int block_threads;        // workgroup size (64, 128 or 256)
   int xcd_run;              // blocks per XCD run in the tile order (kernels.hip tile_pixel)
-  int refill_min;           // persistent mode: dead lanes per wave that trigger a refill (1..64)
+  int refill_min;           // persistent modes: dead lanes per wave that trigger a refill (1..64)
+  int blas_min;             // mode 3: lanes parked in BLAS before the traversal phase is scheduled (1..64)
+  int blas_exit;            // mode 3: the traversal phase yields when fewer lanes than this are still traversing (1..64)
 };
 
 static constexpr int kCounterShards = 256;   // power of two; a block adds to shard blockIdx & (N-1)
 struct alignas(128) DevCounters {            // one shard = one 128-byte line of 64-bit counters
   unsigned long long rays, tlas_nodes, blas_nodes, tri_tests, sphere_tests;
-  unsigned long long hit_tri, hit_sphere, hit_ground, hit_sky, pixels;
+  unsigned long long hit_tri, hit_sphere, hit_ground, hit_sky;
+  unsigned long long watchdog;   // waves that left a persistent kernel through its iteration cap (must stay 0)
 };
 
 // path state of the wavefront pipeline: 4 x float4 per path, SoA by record
