@@ -63,7 +63,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="C3", help="BASELINE.json config to trace (C2..C5); the metric is quoted on C3")
-    ap.add_argument("--kernel-mode", type=int, default=None, help="0 per-pixel, 1 per-bounce queues, 2 persistent (default)")
+    ap.add_argument("--kernel-mode", type=int, default=None, help="0 per-pixel, 1 per-bounce queues, 2 persistent, 3 persistent + phase-scheduled lanes (default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -169,7 +169,7 @@ def main():
                     traffic = j.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        roofline = {"bound": "hbm", "kernel": "trace (k_persist / k_mega / k_bounce by kernel_mode)", "achieved": round(achieved, 1),
+        roofline = {"bound": "hbm", "kernel": "trace: k_sched (kernel_mode 3; 2 = k_persist, 0 = k_mega, 1 = k_bounce)", "achieved": round(achieved, 1),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "algorithmic_bytes_per_launch": int(alg), "kernel_ms": round(kernel_ms, 4),
                     "bytes_per_ray": round(alg * cc["dispatches"] / max(1, cc["rays"]), 1)}
@@ -198,7 +198,7 @@ def main():
                                    f"ground plane, equirect sky; numBounces {scene.num_bounces}, numRays {scene.num_rays}",
                        "frame": [width, height], "pixels_per_gpu": width * height // world,
                        "partition": "8-row strips round-robin over ranks, one gather per frame" if world > 1 else "single GPU",
-                       "rays_per_step": int(total_rays / args.steps), "kernel_mode": args.kernel_mode if args.kernel_mode is not None else 2},
+                       "rays_per_step": int(total_rays / args.steps), "kernel_mode": args.kernel_mode if args.kernel_mode is not None else 3},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

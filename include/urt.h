@@ -144,8 +144,10 @@ typedef struct urt_counters {
 /* Options: "count_stats" (0/1: per-dispatch traversal counters, slower build of the kernel),
  *          "time_dispatch" (0/1: bracket each dispatch with HIP events, read by urt_get_counters),
  *          "kernel_mode" (0 = one thread per pixel; 1 = one launch per bounce over compacted path queues;
- *                         2 = persistent waves with in-wave path regeneration, the default),
- *          "block_threads" (64 | 128 | 256), "xcd_run" (>= 1), "refill_min" (1..64), "waves_per_cu" (1..32)
+ *                         2 = persistent waves with in-wave path regeneration;
+ *                         3 = 2 + lanes scheduled by phase inside the wave, the default),
+ *          "block_threads" (64 | 128 | 256), "xcd_run" (>= 1), "refill_min" (1..64), "waves_per_cu" (1..32),
+ *          "blas_min" / "blas_exit" (1..64, mode 3), "tile_order" (0/1, mode 3: start last frame's expensive tiles first)
  *          — tuning knobs; they change speed only, never pixels. */
 URT_API int urt_set_option(urt_context* ctx, const char* name, int value);
 URT_API int urt_get_counters(urt_context* ctx, urt_counters* out);   /* synchronises */
