@@ -74,6 +74,35 @@ __device__ __forceinline__ void intersect_sphere(const DevScene& S, int idx, v3 
   if (t > 0 && t < best.t) { best.t = t; best.kind = 2; best.id = idx; }
 }
 
+// The triangles of one BVH leaf: Moller-Trumbore with back-face culling, RS:199-234 (edge1/edge2 pre-subtracted on
+// upload), and the closer-hit rule RS:251 extended by "equal t inside one IntersectMeshObject call goes to the lower
+// index slot" (A.4) — `best_i` is the index slot of a hit made in THIS call, or -1.
+template <bool COUNT>
+__device__ __forceinline__ void test_leaf(const DevScene& S, int32_t leaf, v3 o, v3 d, HitRec& best, int& best_i, LocalCounters& lc) {
+  uint32_t code = ~(uint32_t)leaf;
+  uint32_t first = code >> 3, cnt = (code & 7u) + 1u;
+  for (uint32_t k = 0; k < cnt; k++) {
+    if (COUNT) lc.tri_tests++;
+    const float4* tv = S.tri_verts + 3 * (size_t)(first + k);
+    float4 r0 = tv[0], r1 = tv[1], r2 = tv[2];
+    v3 edge1 = xyz(r1), edge2 = xyz(r2);
+    v3 pvec = cross(d, edge2);
+    float det = dot(edge1, pvec);
+    if (det < kEPSILON) continue;
+    float inv_det = 1.0f / det;
+    v3 tvec = o - xyz(r0);
+    float u = dot(tvec, pvec) * inv_det;
+    if (u < 0.0f || u > 1.0f) continue;
+    v3 qvec = cross(tvec, edge1);
+    float v = dot(d, qvec) * inv_det;
+    if (v < 0.0f || u + v > 1.0f) continue;
+    float t = dot(edge2, qvec) * inv_det;
+    int islot = as_int(r0.w);
+    bool closer = (t > 0 && t < best.t) || (t > 0 && t == best.t && best_i >= 0 && islot < best_i);
+    if (closer) { best.t = t; best.kind = 3; best.id = (int)(first + k); best.u = u; best.v = v; best_i = islot; }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // triangle BVH traversal for one MeshObject.  Replaces the brute-force loop RS:243-266 and returns
 // the same winner: minimum t, ties inside one call going to the lowest index slot (A.4).
@@ -126,29 +155,7 @@ __device__ __forceinline__ void intersect_mesh(const DevScene& S, int32_t root, 
         cur = stk[sp * 64];
       }
     } else {
-      uint32_t code = ~(uint32_t)cur;
-      uint32_t first = code >> 3, cnt = (code & 7u) + 1u;
-      for (uint32_t k = 0; k < cnt; k++) {
-        if (COUNT) lc.tri_tests++;
-        const float4* tv = S.tri_verts + 3 * (size_t)(first + k);
-        float4 r0 = tv[0], r1 = tv[1], r2 = tv[2];
-        // Moller-Trumbore with back-face culling, RS:199-234 (edge1/edge2 pre-subtracted on upload)
-        v3 edge1 = xyz(r1), edge2 = xyz(r2);
-        v3 pvec = cross(d, edge2);
-        float det = dot(edge1, pvec);
-        if (det < kEPSILON) continue;
-        float inv_det = 1.0f / det;
-        v3 tvec = o - xyz(r0);
-        float u = dot(tvec, pvec) * inv_det;
-        if (u < 0.0f || u > 1.0f) continue;
-        v3 qvec = cross(tvec, edge1);
-        float v = dot(d, qvec) * inv_det;
-        if (v < 0.0f || u + v > 1.0f) continue;
-        float t = dot(edge2, qvec) * inv_det;
-        int islot = as_int(r0.w);
-        bool closer = (t > 0 && t < best.t) || (t > 0 && t == best.t && best_i >= 0 && islot < best_i);  // RS:251 + A.4
-        if (closer) { best.t = t; best.kind = 3; best.id = (int)(first + k); best.u = u; best.v = v; best_i = islot; }
-      }
+      test_leaf<COUNT>(S, cur, o, d, best, best_i, lc);
       if (sp == 0) break;
       sp--;
       cur = stk[sp * 64];
@@ -317,18 +324,41 @@ __device__ __forceinline__ bool shade(const DevScene& S, const HitRec& h, v3& o,
   return any_nonzero(energy);
 }
 
-// CreateCameraRay RS:142-153 with the uv of RS:448-449
+// Cold per-pixel uniforms (the two camera matrices, 128 B) are read from the kernel-argument segment AT USE through a
+// laundered pointer instead of living in 32 SGPRs for the whole kernel: with them resident the register allocator spilled
+// and re-loaded the hot BVH pointers inside the traversal loop (an s_load + s_waitcnt on every node step).
+typedef const __attribute__((address_space(4))) float* kfloatp;
+__device__ __forceinline__ kfloatp kernarg_floats(unsigned byte_offset) {
+  const __attribute__((address_space(4))) char* p = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+  p += byte_offset;
+  asm volatile("" : "+s"(p));                      // opaque to LICM: the loads below stay where they are written
+  return (kfloatp)p;
+}
+__device__ __forceinline__ v3 mul_m4_k(kfloatp m, float x, float y, float z, float w) {   // urt::mul_m4 on a kernarg matrix
+  v3 r;
+  r.x = f_fma(m[12], w, f_fma(m[8], z, f_fma(m[4], y, m[0] * x)));
+  r.y = f_fma(m[13], w, f_fma(m[9], z, f_fma(m[5], y, m[1] * x)));
+  r.z = f_fma(m[14], w, f_fma(m[10], z, f_fma(m[6], y, m[2] * x)));
+  return r;
+}
+
+// CreateCameraRay RS:142-153 with the uv of RS:448-449.  p_off = byte offset of the FrameParams argument in the kernarg segment.
+template <unsigned P_OFF>
 __device__ __forceinline__ void camera_ray(const FrameParams& P, int x, int y, float& seed, v3& o, v3& d) {
   float px = (float)x, py = (float)y;
   float r0 = rand_next(seed, px, py);
   float r1 = rand_next(seed, px, py);
   float u = (px + r0 + P.pixel_off_x) / (float)P.width * 2.0f - 1.0f;
   float v = (py + r1 + P.pixel_off_y) / (float)P.height * 2.0f - 1.0f;
-  o = mul_m4(P.c2w, 0.0f, 0.0f, 0.0f, 1.0f);
-  v3 dir = mul_m4(P.invp, u, v, 0.0f, 1.0f);
-  dir = mul_m4(P.c2w, dir.x, dir.y, dir.z, 0.0f);
+  kfloatp c2w = kernarg_floats(P_OFF + (unsigned)__builtin_offsetof(FrameParams, c2w));
+  kfloatp invp = kernarg_floats(P_OFF + (unsigned)__builtin_offsetof(FrameParams, invp));
+  o = mul_m4_k(c2w, 0.0f, 0.0f, 0.0f, 1.0f);
+  v3 dir = mul_m4_k(invp, u, v, 0.0f, 1.0f);
+  dir = mul_m4_k(c2w, dir.x, dir.y, dir.z, 0.0f);
   d = normalize(dir);
 }
+// kernels take (DevScene, FrameParams, ...) or (FrameParams, ...): by-value aggregates are laid out like C struct members
+static constexpr unsigned kPOffAfterScene = (unsigned)((sizeof(DevScene) + alignof(FrameParams) - 1) / alignof(FrameParams) * alignof(FrameParams));
 
 // tile -> pixel: one 8x8 tile per wave (the reference's [numthreads(8,8,1)] group, RS:431).
 // Blocks are dealt round-robin to the 8 XCDs (b % 8 shares an XCD, each XCD has a private 4 MiB L2).
@@ -404,7 +434,7 @@ __global__ __launch_bounds__(256) void k_mega(DevScene S, FrameParams P, float4*
     for (int i = 0; i < P.num_rays; i++) {
       v3 res = mk3(0, 0, 0);
       v3 o, d, energy = mk3(1, 1, 1);
-      camera_ray(P, x, y, seed, o, d);
+      camera_ray<kPOffAfterScene>(P, x, y, seed, o, d);
       for (int k = 0; k < P.num_bounces; k++) {
         HitRec h = trace<COUNT>(S, o, d, tl, bl, lc);
         if (!shade<COUNT>(S, h, o, d, energy, res, seed, px, py, lc)) break;
@@ -466,7 +496,7 @@ __global__ __launch_bounds__(256) void k_persist(DevScene S, FrameParams P, floa
             px = (float)x; py = (float)y;
             seed = P.seed; ray_i = 0; k = 0;
             avg = mk3(0, 0, 0); res = mk3(0, 0, 0); energy = mk3(1, 1, 1);
-            camera_ray(P, x, y, seed, o, d);
+            camera_ray<kPOffAfterScene>(P, x, y, seed, o, d);
           }
         }
       }
@@ -487,7 +517,7 @@ __global__ __launch_bounds__(256) void k_persist(DevScene S, FrameParams P, floa
         ray_i++;
         if (ray_i < P.num_rays) {                    // RS:444: next ray of this pixel, _Seed carries over
           res = mk3(0, 0, 0); energy = mk3(1, 1, 1); k = 0;
-          camera_ray(P, x, y, seed, o, d);
+          camera_ray<kPOffAfterScene>(P, x, y, seed, o, d);
         } else {
           float n = (float)P.num_rays;
           result[(size_t)y * P.width + x] = make_float4(avg.x / n, avg.y / n, avg.z / n, 1.0f);   // RS:468
@@ -571,7 +601,7 @@ __global__ __launch_bounds__(256) void k_sched(DevScene S, FrameParams P, float4
             st = ST_FRONT;
             seed = P.seed; ray_i = 0; k = 0; steps_px = 0;
             avg = mk3(0, 0, 0); res = mk3(0, 0, 0); energy = mk3(1, 1, 1);
-            camera_ray(P, x, y, seed, o, d);
+            camera_ray<kPOffAfterScene>(P, x, y, seed, o, d);
           }
         }
       }
@@ -607,7 +637,7 @@ __global__ __launch_bounds__(256) void k_sched(DevScene S, FrameParams P, float4
               st = ST_FRONT;
               seed = P.seed; ray_i = 0; k = 0;
               avg = mk3(0, 0, 0); res = mk3(0, 0, 0); energy = mk3(1, 1, 1);
-              camera_ray(P, x, y, seed, o, d);
+              camera_ray<kPOffAfterScene>(P, x, y, seed, o, d);
             }
           }
         }
@@ -644,7 +674,10 @@ __global__ __launch_bounds__(256) void k_sched(DevScene S, FrameParams P, float4
           }
           if (seen && index >= 0 && index < S.n_meshes) {
             int32_t root = S.mesh_root[index];
-            if (root != kEmptyMeshRoot) { cur = root; sp = 0; best_i = -1; need_blas = true; break; }
+            if (root < 0 && root != kBlasDone) {               // a mesh of <= 8 triangles is one leaf: test it here, no phase switch
+              int bi_local = -1;
+              test_leaf<COUNT>(S, root, o, d, best, bi_local, lc);
+            } else if (root != kEmptyMeshRoot) { cur = root; sp = 0; best_i = -1; need_blas = true; break; }
           }
         }
         if (need_blas) {
@@ -719,28 +752,7 @@ __global__ __launch_bounds__(256) void k_sched(DevScene S, FrameParams P, float4
               cur = bl[sp * 64];
             }
           } else {
-            uint32_t code = ~(uint32_t)cur;
-            uint32_t first = code >> 3, cnt = (code & 7u) + 1u;
-            for (uint32_t j = 0; j < cnt; j++) {
-              if (COUNT) lc.tri_tests++;
-              const float4* tv = S.tri_verts + 3 * (size_t)(first + j);
-              float4 r0 = tv[0], r1 = tv[1], r2 = tv[2];
-              v3 edge1 = xyz(r1), edge2 = xyz(r2);
-              v3 pvec = cross(d, edge2);
-              float det = dot(edge1, pvec);
-              if (det < kEPSILON) continue;
-              float inv_det = 1.0f / det;
-              v3 tvec = o - xyz(r0);
-              float u = dot(tvec, pvec) * inv_det;
-              if (u < 0.0f || u > 1.0f) continue;
-              v3 qvec = cross(tvec, edge1);
-              float v = dot(d, qvec) * inv_det;
-              if (v < 0.0f || u + v > 1.0f) continue;
-              float t = dot(edge2, qvec) * inv_det;
-              int islot = as_int(r0.w);
-              bool closer = (t > 0 && t < best.t) || (t > 0 && t == best.t && best_i >= 0 && islot < best_i);
-              if (closer) { best.t = t; best.kind = 3; best.id = (int)(first + j); best.u = u; best.v = v; best_i = islot; }
-            }
+            test_leaf<COUNT>(S, cur, o, d, best, best_i, lc);
             if (sp == 0) cur = kBlasDone;
             else { sp--; cur = bl[sp * 64]; }
           }
@@ -760,7 +772,7 @@ __global__ __launch_bounds__(256) void k_sched(DevScene S, FrameParams P, float4
           ray_i++;
           if (ray_i < P.num_rays) {
             res = mk3(0, 0, 0); energy = mk3(1, 1, 1); k = 0;
-            camera_ray(P, x, y, seed, o, d);
+            camera_ray<kPOffAfterScene>(P, x, y, seed, o, d);
           } else {
             float n = (float)P.num_rays;
             result[(size_t)y * P.width + x] = make_float4(avg.x / n, avg.y / n, avg.z / n, 1.0f);
@@ -841,7 +853,7 @@ __global__ __launch_bounds__(256) void k_generate(FrameParams P, PathQueues Q, c
   v3 o = mk3(0, 0, 0), d = mk3(0, 0, 0);
   if (ok) {
     if (ray_index > 0) seed = result[(size_t)y * P.width + x].w;
-    camera_ray(P, x, y, seed, o, d);
+    camera_ray<0>(P, x, y, seed, o, d);
   }
   unsigned int* cnt = Q.counts + (size_t)ray_index * (P.num_bounces + 1);
   int slot = wave_append(ok, cnt);
