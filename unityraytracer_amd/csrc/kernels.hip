@@ -714,12 +714,18 @@ __global__ __launch_bounds__(256) void k_sched(DevScene S, FrameParams P, float4
       v3 nom = mk3(-((o.x - pad) * idir.x), -((o.y - pad) * idir.y), -((o.z - pad) * idir.z));
       bool active = mine && cur != kBlasDone;
       unsigned int steps = 0;
-      while (__popcll(__ballot(active)) >= exit_below) {
+      for (;;) {
+        unsigned long long mA = __ballot(active);
+        if (__popcll(mA) < exit_below) break;
         if (++steps > kWatchdogSteps) { watchdog = true; break; }
-        if (active) {
-          // descend interior nodes until this lane holds a leaf (or is done)
-          steps_px++;
-          if (cur >= 0) {
+        // majority vote: this trip runs EITHER the interior-node step OR the leaf step, for the lanes that hold that kind
+        // of cursor (the others wait one trip) — so a trip costs one of the two bodies, not their sum.
+        bool interior = active && cur >= 0;
+        int nI = __popcll(__ballot(interior));
+        int nL = __popcll(mA) - nI;
+        if (nI >= nL) {
+          if (interior) {
+            steps_px++;
             if (COUNT) lc.blas_nodes++;
             const float4* n = S.blas_nodes + 4 * (size_t)cur;
             float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
@@ -751,13 +757,16 @@ __global__ __launch_bounds__(256) void k_sched(DevScene S, FrameParams P, float4
               sp--;
               cur = bl[sp * 64];
             }
-          } else {
+          }
+        } else {
+          if (active && !interior) {
+            steps_px++;
             test_leaf<COUNT>(S, cur, o, d, best, best_i, lc);
             if (sp == 0) cur = kBlasDone;
             else { sp--; cur = bl[sp * 64]; }
           }
-          active = cur != kBlasDone;
         }
+        active = mine && cur != kBlasDone;
       }
       if (mine && cur == kBlasDone) st = ST_RESUME;               // back to the heap walk (RS:323-325 continues)
     } else {
