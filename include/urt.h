@@ -147,7 +147,7 @@ typedef struct urt_counters {
  *                         2 = persistent waves with in-wave path regeneration;
  *                         3 = 2 + lanes scheduled by phase inside the wave, the default),
  *          "block_threads" (64 | 128 | 256), "xcd_run" (>= 1), "refill_min" (1..64), "waves_per_cu" (1..32),
- *          "blas_min" / "blas_exit" (1..64, mode 3), "tile_order" (0/1, mode 3: start last frame's expensive tiles first)
+ *          "blas_min" / "blas_exit" (1..64, mode 3)
  *          — tuning knobs; they change speed only, never pixels. */
 URT_API int urt_set_option(urt_context* ctx, const char* name, int value);
 URT_API int urt_get_counters(urt_context* ctx, urt_counters* out);   /* synchronises */

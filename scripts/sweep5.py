@@ -19,5 +19,5 @@ for (w, h) in ((1920, 1080), (3840, 2160)):
         c = ctx.counters()
         print(f"{w}x{h} {label}: trace {c['trace_ms']/10:7.3f} ms wall {wall*1e3:7.3f} ms {c['rays']/c['trace_ms']/1e3:8.1f} Mrays/s wd {c['watchdog_trips']}", flush=True)
         m.OnDisable()
-    for to, rf, bmin in itertools.product((0, 1), (32, 48), (16, 24)):
-        run(f"sched(3) tile_order {to} refill {rf} blas_min {bmin}", kernel_mode=3, tile_order=to, refill_min=rf, blas_min=bmin, blas_exit=8, waves_per_cu=16)
+    for to, rf, bmin in itertools.product((0,), (32, 48, 56, 64), (8, 16, 24)):
+        run(f"sched(3) tile_order {to} refill {rf} blas_min {bmin}", kernel_mode=3, refill_min=rf, blas_min=bmin, blas_exit=8, waves_per_cu=16)

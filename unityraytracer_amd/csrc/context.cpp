@@ -81,17 +81,13 @@ struct urt_context {
   unsigned int* d_next = nullptr;           // persistent mode: frame work counter
   uint64_t pixels_dispatched = 0;
   int n_cus = 256;
-  // cost-ordered tile schedule (mode 3): previous frame's per-tile traversal steps -> heavy tiles first
-  unsigned int* d_tile_order = nullptr;
-  unsigned int* d_tile_cost = nullptr;
-  size_t tile_capacity = 0;
-  long long tile_shape_key = -1;            // (tiles_x, n_strips, first_row, row_stride, W, H) of the frame the cost belongs to
+
   uint64_t dispatches = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> timing;   // unresolved event pairs
   float trace_ms = 0;
 
   int opt_count_stats = 0, opt_time_dispatch = 0, opt_kernel_mode = 3;
-  int opt_block_threads = 64, opt_xcd_run = 1, opt_refill_min = 48, opt_waves_per_cu = 16, opt_blas_min = 16, opt_blas_exit = 8, opt_tile_order = 0;   // tile_order measured slower (heavy tiles together thrash): off
+  int opt_block_threads = 64, opt_xcd_run = 1, opt_refill_min = 48, opt_waves_per_cu = 16, opt_blas_min = 16, opt_blas_exit = 8;
 };
 
 namespace {
@@ -347,27 +343,8 @@ int do_dispatch(urt_context* ctx, int kernel, int gx, int gy, int gz, int first_
     long want = ((long)P.tiles_x * P.n_strips + waves_per_block - 1) / waves_per_block;
     long resident = (long)ctx->n_cus * ctx->opt_waves_per_cu / waves_per_block;
     int nb = (int)std::max(1L, std::min(want, resident));
-    if (mode == 2) le = launch_persist(S, P, res->dev, ctx->d_counters, ctx->d_next, nb, count, ctx->stream);
-    else {
-      unsigned int *ord = nullptr, *cst = nullptr;
-      bool valid = false;
-      if (ctx->opt_tile_order) {
-        size_t ntiles = (size_t)P.tiles_x * (size_t)P.n_strips;
-        if (ntiles > ctx->tile_capacity) {
-          if (ctx->d_tile_order) (void)hipFree(ctx->d_tile_order);
-          if (ctx->d_tile_cost) (void)hipFree(ctx->d_tile_cost);
-          ctx->d_tile_order = ctx->d_tile_cost = nullptr; ctx->tile_capacity = 0; ctx->tile_shape_key = -1;
-          URT_HIP(ctx, hipMalloc((void**)&ctx->d_tile_order, ntiles * sizeof(unsigned int)));
-          URT_HIP(ctx, hipMalloc((void**)&ctx->d_tile_cost, ntiles * sizeof(unsigned int)));
-          ctx->tile_capacity = ntiles;
-        }
-        long long key = ((((long long)P.tiles_x * 65537 + P.n_strips) * 65537 + P.first_group_row) * 257 + P.row_stride) * 65537 + P.width * 3 + P.height;
-        valid = key == ctx->tile_shape_key;
-        ctx->tile_shape_key = key;
-        ord = ctx->d_tile_order; cst = ctx->d_tile_cost;
-      }
-      le = launch_sched(S, P, res->dev, ctx->d_counters, ctx->d_next, ord, cst, valid, nb, count, ctx->stream);
-    }
+    le = mode == 2 ? launch_persist(S, P, res->dev, ctx->d_counters, ctx->d_next, nb, count, ctx->stream)
+                   : launch_sched(S, P, res->dev, ctx->d_counters, ctx->d_next, nb, count, ctx->stream);
   } else le = launch_mega(S, P, res->dev, ctx->d_counters, count, ctx->stream);
   if (ctx->opt_time_dispatch) {
     (void)hipEventRecord(e1, ctx->stream);
@@ -429,8 +406,6 @@ int urt_context_destroy(urt_context* ctx) {
   if (ctx->zero_sky) (void)hipFree(ctx->zero_sky);
   if (ctx->d_counters) (void)hipFree(ctx->d_counters);
   if (ctx->d_next) (void)hipFree(ctx->d_next);
-  if (ctx->d_tile_order) (void)hipFree(ctx->d_tile_order);
-  if (ctx->d_tile_cost) (void)hipFree(ctx->d_tile_cost);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
   return URT_OK;
@@ -710,9 +685,6 @@ int urt_set_option(urt_context* ctx, const char* name, int value) {
   } else if (std::strcmp(name, "block_threads") == 0) {
     if (value != 64 && value != 128 && value != 256) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "block_threads must be 64, 128 or 256");
     ctx->opt_block_threads = value;
-  } else if (std::strcmp(name, "tile_order") == 0) {
-    ctx->opt_tile_order = value ? 1 : 0;
-    ctx->tile_shape_key = -1;
   } else if (std::strcmp(name, "blas_min") == 0) {
     if (value < 1 || value > 64) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "blas_min must be in [1, 64]");
     ctx->opt_blas_min = value;

@@ -14,10 +14,8 @@ hipError_t launch_wavefront(const DevScene& S, const FrameParams& P, const PathQ
 hipError_t launch_persist(const DevScene& S, const FrameParams& P, float4* result, DevCounters* ctr, unsigned int* next,
                           int n_blocks, bool count, hipStream_t st);
 // mode 3: persistent waves whose lanes are scheduled by phase (FRONT / BLAS / SHADE) inside the wave
-// order/cost: per-tile buffers (capacity >= tiles of the dispatch) for the cost-ordered tile schedule, or NULL;
-// order_valid: cost holds the previous frame of the SAME dispatch shape.
 hipError_t launch_sched(const DevScene& S, const FrameParams& P, float4* result, DevCounters* ctr, unsigned int* next,
-                        unsigned int* order, unsigned int* cost, bool order_valid, int n_blocks, bool count, hipStream_t st);
+                        int n_blocks, bool count, hipStream_t st);
 // AdditionShader blend (AS:9,39-41)
 hipError_t launch_blit_add(const float4* src, float4* dst, size_t n_pixels, float sample, hipStream_t st);
 // strips <-> dense buffer

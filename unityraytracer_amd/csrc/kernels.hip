@@ -557,8 +557,7 @@ static constexpr unsigned int kWatchdogSteps = 1u << 24;    // traversal steps p
 
 template <bool COUNT>
 __global__ __launch_bounds__(256) void k_sched(DevScene S, FrameParams P, float4* __restrict__ result, DevCounters* ctr,
-                                               unsigned int* __restrict__ next, const unsigned int* __restrict__ order,
-                                               unsigned int* __restrict__ cost) {
+                                               unsigned int* __restrict__ next) {
   int *tl, *bl;
   lane_stacks(P, tl, bl);
   LocalCounters lc;
@@ -576,7 +575,6 @@ __global__ __launch_bounds__(256) void k_sched(DevScene S, FrameParams P, float4
   int check = 0; bool seen = false;              // object-level heap walk (RS:294-326)
   int32_t cur = kBlasDone; int sp = 0, best_i = -1;   // triangle-BVH cursor of the current MeshObject
   unsigned int wave_iters = 0;
-  unsigned int steps_px = 0;                     // traversal steps of the current pixel (cost feedback for the tile order)
   bool watchdog = false;
 
   for (;;) {
@@ -593,13 +591,12 @@ __global__ __launch_bounds__(256) void k_sched(DevScene S, FrameParams P, float4
         unsigned int idx = base + (unsigned int)__popcll(mD & lt_mask);
         if (idx < total) {
           int tile = (int)(idx >> 6), l = (int)(idx & 63u);
-          if (order) tile = (int)order[tile];          // heavy tiles of the previous frame first (speed only)
           int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
           x = tx * 8 + (l & 7);
           y = (P.first_group_row + ty * P.row_stride) * 8 + (l >> 3);
           if (x < P.region_w && y < P.region_h) {
             st = ST_FRONT;
-            seed = P.seed; ray_i = 0; k = 0; steps_px = 0;
+            seed = P.seed; ray_i = 0; k = 0;
             avg = mk3(0, 0, 0); res = mk3(0, 0, 0); energy = mk3(1, 1, 1);
             camera_ray<kPOffAfterScene>(P, x, y, seed, o, d);
           }
@@ -629,7 +626,6 @@ __global__ __launch_bounds__(256) void k_sched(DevScene S, FrameParams P, float4
           unsigned int idx = base + (unsigned int)__popcll(m2 & lt_mask);
           if (idx < total) {
             int tile = (int)(idx >> 6), l = (int)(idx & 63u);
-          if (order) tile = (int)order[tile];          // heavy tiles of the previous frame first (speed only)
             int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
             x = tx * 8 + (l & 7);
             y = (P.first_group_row + ty * P.row_stride) * 8 + (l >> 3);
@@ -725,7 +721,6 @@ __global__ __launch_bounds__(256) void k_sched(DevScene S, FrameParams P, float4
         int nL = __popcll(mA) - nI;
         if (nI >= nL) {
           if (interior) {
-            steps_px++;
             if (COUNT) lc.blas_nodes++;
             const float4* n = S.blas_nodes + 4 * (size_t)cur;
             float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
@@ -760,7 +755,6 @@ __global__ __launch_bounds__(256) void k_sched(DevScene S, FrameParams P, float4
           }
         } else {
           if (active && !interior) {
-            steps_px++;
             test_leaf<COUNT>(S, cur, o, d, best, best_i, lc);
             if (sp == 0) cur = kBlasDone;
             else { sp--; cur = bl[sp * 64]; }
@@ -786,10 +780,6 @@ __global__ __launch_bounds__(256) void k_sched(DevScene S, FrameParams P, float4
             float n = (float)P.num_rays;
             result[(size_t)y * P.width + x] = make_float4(avg.x / n, avg.y / n, avg.z / n, 1.0f);
             st = ST_DEAD;
-            if (cost && steps_px) {
-              int t = (((y >> 3) - P.first_group_row) / P.row_stride) * P.tiles_x + (x >> 3);
-              atomicAdd(&cost[t], steps_px);
-            }
           }
         }
       }
@@ -797,30 +787,6 @@ __global__ __launch_bounds__(256) void k_sched(DevScene S, FrameParams P, float4
   }
   if (watchdog && lane == 0) atomicAdd(&ctr->watchdog, 1ull);
   flush_counters<COUNT>(lc, ctr);
-}
-
-// Tile order for the next frame of a progressive render: tiles whose pixels needed triangle-BVH steps in the previous
-// frame come first (in index order, so neighbours stay together), the rest after them.  With the long multi-bounce paths
-// started early, the frame no longer ends on a tail of a few slow waves.  One workgroup, stable two-way partition.
-__global__ __launch_bounds__(1024) void k_tile_order(const unsigned int* __restrict__ cost, unsigned int* __restrict__ order, int ntiles) {
-  __shared__ unsigned int s_wave[16];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // thread t owns the contiguous tile range [lo, hi): count its heavy tiles, block-wide exclusive scan, stable scatter
-  const int per = (ntiles + 1023) / 1024;
-  const int lo = min(tid * per, ntiles), hi = min(lo + per, ntiles);
-  unsigned int mine = 0;
-  for (int t = lo; t < hi; t++) mine += cost[t] ? 1u : 0u;
-  unsigned int incl = mine;                                   // inclusive scan inside the wave
-  for (int off = 1; off < 64; off <<= 1) { unsigned int v = __shfl_up(incl, off, 64); if (lane >= off) incl += v; }
-  if (lane == 63) s_wave[wave] = incl;
-  __syncthreads();
-  unsigned int before = 0, total = 0;
-  for (int w = 0; w < 16; w++) { unsigned int v = s_wave[w]; if (w < wave) before += v; total += v; }
-  unsigned int ph = before + incl - mine;                     // heavy tiles in ranges before mine
-  unsigned int pl = total + ((unsigned int)lo - ph);          // light tiles before mine, placed after all heavy ones
-  for (int t = lo; t < hi; t++) {
-    if (cost[t]) order[ph++] = (unsigned int)t; else order[pl++] = (unsigned int)t;
-  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1002,21 +968,13 @@ hipError_t launch_persist(const DevScene& S, const FrameParams& P, float4* resul
 }
 
 hipError_t launch_sched(const DevScene& S, const FrameParams& P, float4* result, DevCounters* ctr, unsigned int* next,
-                        unsigned int* order, unsigned int* cost, bool order_valid, int n_blocks, bool count, hipStream_t st) {
+                        int n_blocks, bool count, hipStream_t st) {
   if (n_blocks <= 0) return hipSuccess;
   hipError_t e = hipMemsetAsync(next, 0, sizeof(unsigned int), st);
   if (e != hipSuccess) return e;
-  int ntiles = P.tiles_x * P.n_strips;
-  if (cost) {
-    // order <- partition by the previous frame's cost; then clear cost for this frame's feedback
-    if (order_valid) hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, st, (const unsigned int*)cost, order, ntiles);
-    e = hipMemsetAsync(cost, 0, (size_t)ntiles * sizeof(unsigned int), st);
-    if (e != hipSuccess) return e;
-  }
-  const unsigned int* ord = (cost && order_valid) ? order : nullptr;
   size_t lds = stack_lds_bytes(P);
-  if (count) hipLaunchKernelGGL(k_sched<true>, dim3(n_blocks), dim3(P.block_threads), lds, st, S, P, result, ctr, next, ord, cost);
-  else hipLaunchKernelGGL(k_sched<false>, dim3(n_blocks), dim3(P.block_threads), lds, st, S, P, result, ctr, next, ord, cost);
+  if (count) hipLaunchKernelGGL(k_sched<true>, dim3(n_blocks), dim3(P.block_threads), lds, st, S, P, result, ctr, next);
+  else hipLaunchKernelGGL(k_sched<false>, dim3(n_blocks), dim3(P.block_threads), lds, st, S, P, result, ctr, next);
   return hipGetLastError();
 }
 
