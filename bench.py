@@ -82,11 +82,18 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # URT_DIST_BACKEND=gloo is a REHEARSAL mode for boxes with fewer GPUs than ranks (ranks share a card, the gather is
+    # staged through host memory); the driver's real multi-GPU runs use nccl (= RCCL over xGMI), one GPU per rank.
+    backend = os.environ.get("URT_DIST_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     # ---- workload --------------------------------------------------------------------------------
     base_w, base_h = (1920, 1080) if args.config in ("C2", "C3") else (3840, 2160)
@@ -94,7 +101,7 @@ def main():
     width, height = int(round(base_w * s)), int(round(base_h * s))
     scene = scenes.CONFIGS[args.config](width, height)
 
-    ctx = Context(local_rank)
+    ctx = Context(dev_index)
     ctx.set_stream(torch.cuda.current_stream(device).cuda_stream)      # one in-order stream for kernels + collective
     if args.kernel_mode is not None:
         ctx.set_option("kernel_mode", args.kernel_mode)
@@ -115,7 +122,16 @@ def main():
         master.OnRenderImage()
         if world > 1:
             master._converged.pack_rows(rank, world, packed.data_ptr())
-            dist.gather(packed, gathered, dst=0)
+            if backend == "nccl":
+                dist.gather(packed, gathered, dst=0)                    # the ONE collective of the frame
+            else:                                                       # rehearsal: same data path through host memory
+                torch.cuda.synchronize(device)
+                host = packed.cpu()
+                parts = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
+                dist.gather(host, parts, dst=0)
+                if rank == 0:
+                    for r in range(world):
+                        gathered[r].copy_(parts[r])
             if rank == 0:
                 for r in range(world):
                     full.unpack_rows(r, world, gathered[r].data_ptr())
@@ -136,8 +152,9 @@ def main():
     elapsed = time.perf_counter() - t0
     c = ctx.counters()
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    rays = torch.tensor([float(c["rays"])], dtype=torch.float64, device=device)
+    red_dev = device if backend == "nccl" else torch.device("cpu")
+    t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    rays = torch.tensor([float(c["rays"])], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
@@ -189,6 +206,22 @@ def main():
             cpu = {"value": round(oc["rays"] / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
                    "sample": f"1 frame of {scene.name} {width}x{height} (frame 0 uniforms), BVH-culled scalar oracle, {cores} std::threads"}
 
+    if world > 1 and os.environ.get("URT_BENCH_VERIFY") == "1":
+        # rank 0 re-renders the LAST frame alone and compares the gathered, accumulated image bit for bit
+        fence()
+        if rank == 0:
+            import numpy as np
+            got = full.GetPixels()
+            solo = RayTraceMaster(ctx, scene)
+            for _ in range(args.warmup + args.steps):      # `full` holds the gather of the last TIMED step
+                solo.OnRenderImage()
+            want = solo._converged.GetPixels()
+            solo.OnDisable()
+            same = bool(np.array_equal(got.view(np.uint32), want.view(np.uint32)))
+            print(f"[verify] gathered {world}-rank frame == single-rank frame: {same}", file=sys.stderr, flush=True)
+            if not same:
+                raise SystemExit("multi-rank image differs from the single-rank image")
+        fence()
     if rank == 0:
         out = {
             "metric": "Mrays/sec @1920x1080, 8 bounces", "value": round(total_rays / elapsed / 1e6, 2), "unit": "Mrays/s",
