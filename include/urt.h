@@ -153,6 +153,26 @@ URT_API int urt_set_option(urt_context* ctx, const char* name, int value);
 URT_API int urt_get_counters(urt_context* ctx, urt_counters* out);   /* synchronises */
 URT_API int urt_reset_counters(urt_context* ctx);
 
+/* ---- host-side scene preparation (no GPU needed) ---------------------- */
+/* RayTraceMaster.ComputeNormals (RM:340-368): per-vertex sum of the un-normalised face normals of every index slot whose
+ * vertex POSITION equals this vertex's (weld across all meshes), in ascending slot order, then Vector3.Normalize —
+ * O(V + I) by position hashing instead of the reference's O(V * I).  out_normals = 3 * n_vertices floats. */
+URT_API int urt_host_compute_normals(const float* vertices, int n_vertices, const int32_t* indices, int n_indices,
+                                     float* out_normals);
+/* SetupBVHLeaves(List<MeshObject>) (RM:405-433): one world-space box per MeshObject (112-B records).  literal != 0 keeps
+ * the reference's quirks (box seeded from _vertices[_indices[0]], the mesh's own first index slot skipped, A.7);
+ * literal == 0 gives the tight box. */
+URT_API int urt_host_mesh_leaf_bounds(const void* mesh_objects, int n_meshes, const float* vertices, int n_vertices,
+                                      const int32_t* indices, int n_indices, int literal, urt_BVHNode* out_leaves);
+/* SetupBVHLeaves(List<Sphere>) (RM:436-455): literal != 0 keeps the inverted boxes (vmin = pos + r, vmax = pos - r). */
+URT_API int urt_host_sphere_leaf_bounds(const void* spheres, int n_spheres, int literal, urt_BVHNode* out_leaves);
+/* CreateBVH's output contract (RM:681-722): implicit heap of 2^D - 1 nodes, D = ceil(log2 n) + 1, children 2i+1 / 2i+2,
+ * interior and filler nodes index -1 (fillers all-zero, RM:490-494).  The tree is a deterministic median split (the
+ * reference's pairing heuristic RM:510-678 depends on .NET's unstable sort and is not reproducible). */
+URT_API int urt_host_object_bvh_length(int n_objects);
+URT_API int urt_host_build_object_bvh(const urt_BVHNode* leaves, int n_objects, urt_BVHNode* out_nodes, int capacity);
+URT_API const char* urt_host_last_error(void);
+
 /* ---- introspection for tests (host only, no GPU needed) ------------------------------------ */
 /* Run the library's triangle-BVH builder — the one urt_shader_dispatch uses — over host copies of
  * _MeshObjects (112 B records), _Vertices, _Indices, and keep the result in a process-wide cache.

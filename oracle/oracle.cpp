@@ -25,6 +25,7 @@
 //      oracle_build_blas below).  A conservative BVH only skips triangles that cannot win, and the
 //      (t, index) rule below reproduces the brute-force winner; tests prove mode 1 == mode 0.
 #include <atomic>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <thread>
@@ -635,6 +636,69 @@ int oracle_build_blas(const OracleScene* scene, float* nodes, int n_nodes_cap, i
     }
   }
   return n_nodes;
+}
+
+// ---- literal restatements of the reference's host-side scene preparation ----------------
+// UnityEngine.Vector3 arithmetic is float32 with separate multiplies and adds.
+namespace {
+struct U3 { float x, y, z; };
+static inline U3 usub(U3 a, U3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+static inline U3 ucross(U3 a, U3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+static inline float usqr(U3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+static inline U3 uld(const float* p) { return {p[0], p[1], p[2]}; }
+static inline U3 umul_point_3x4(const float* m, U3 p) {       // Matrix4x4.MultiplyPoint3x4, column-major storage
+  return {m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12], m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
+          m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14]};
+}
+}  // namespace
+
+// RayTraceMaster.ComputeNormals, RM:340-368, as written: O(V * I).
+void oracle_compute_normals(const float* vertices, int n_vertices, const int32_t* indices, int n_indices, float* out) {
+  const float EPSILON = 3.0f * 1.401298464e-45f;                              // RM:14: float.Epsilon * 3
+  for (int i = 0; i < n_vertices; i++) {
+    U3 vec = {0.0f, 0.0f, 0.0f};                                              // RM:347
+    U3 vi = uld(vertices + 3 * i);
+    for (int listIndex = 0; listIndex < n_indices; listIndex++) {             // RM:350-351: every (vecIndex, listIndex) pair ...
+      int vecIndex = indices[listIndex];
+      if (usqr(usub(uld(vertices + 3 * vecIndex), vi)) <= EPSILON) {          // ... whose vertex coincides with vertex i
+        int start = listIndex - (listIndex % 3);                              // RM:356
+        U3 a = uld(vertices + 3 * indices[start]), b = uld(vertices + 3 * indices[start + 1]), c = uld(vertices + 3 * indices[start + 2]);
+        U3 n = ucross(usub(b, a), usub(c, a));                                // RM:359
+        vec = {vec.x + n.x, vec.y + n.y, vec.z + n.z};
+      }
+    }
+    float mag = std::sqrt(vec.x * vec.x + vec.y * vec.y + vec.z * vec.z);     // Vector3.Normalize (RM:363)
+    if (mag > 1e-5f) { out[3 * i] = vec.x / mag; out[3 * i + 1] = vec.y / mag; out[3 * i + 2] = vec.z / mag; }
+    else { out[3 * i] = out[3 * i + 1] = out[3 * i + 2] = 0.0f; }
+  }
+}
+
+// SetupBVHLeaves(List<MeshObject>), RM:405-433, as written (including the seed from _indices[0] and the skipped first slot).
+void oracle_mesh_leaf_bounds(const urt_MeshObject* meshes, int n_meshes, const float* vertices, const int32_t* indices, urt_BVHNode* out) {
+  for (int m = 0; m < n_meshes; m++) {
+    const urt_MeshObject& mesh = meshes[m];
+    U3 lo = umul_point_3x4(mesh.localToWorldMatrix, uld(vertices + 3 * indices[0]));      // RM:415
+    U3 hi = lo;                                                                            // RM:416
+    for (int i = mesh.indices_offset + 1; i < mesh.indices_offset + mesh.indices_count; i++) {   // RM:421
+      U3 t = umul_point_3x4(mesh.localToWorldMatrix, uld(vertices + 3 * indices[i]));
+      lo = {std::min(lo.x, t.x), std::min(lo.y, t.y), std::min(lo.z, t.z)};
+      hi = {std::max(hi.x, t.x), std::max(hi.y, t.y), std::max(hi.z, t.z)};
+    }
+    out[m].vmin[0] = lo.x; out[m].vmin[1] = lo.y; out[m].vmin[2] = lo.z;
+    out[m].vmax[0] = hi.x; out[m].vmax[1] = hi.y; out[m].vmax[2] = hi.z;
+    out[m].index = m;
+  }
+}
+
+// SetupBVHLeaves(List<Sphere>), RM:436-455, as written (inverted boxes).
+void oracle_sphere_leaf_bounds(const urt_Sphere* spheres, int n_spheres, urt_BVHNode* out) {
+  for (int i = 0; i < n_spheres; i++) {
+    for (int k = 0; k < 3; k++) {
+      out[i].vmin[k] = spheres[i].position[k] - (-spheres[i].radius);          // RM:445
+      out[i].vmax[k] = spheres[i].position[k] - spheres[i].radius;             // RM:446
+    }
+    out[i].index = i;
+  }
 }
 
 int oracle_hardware_threads(void) { return (int)std::thread::hardware_concurrency(); }

@@ -1,0 +1,214 @@
+// host_scene.cpp — host-side scene preparation that RayTraceMaster.cs does in C# before it uploads buffers
+// (SURVEY.md §8f rows f1 and f2).  Pure C++ behind the C ABI, no GPU needed.
+//
+//   urt_host_compute_normals     RayTraceMaster.ComputeNormals (RM:340-368) in O(V + I) instead of O(V * I)
+//   urt_host_mesh_leaf_bounds    SetupBVHLeaves(List<MeshObject>) (RM:405-433), literal incl. its quirks (A.7), or tight
+//   urt_host_sphere_leaf_bounds  SetupBVHLeaves(List<Sphere>) (RM:436-455), literal (inverted boxes) or normalised
+//   urt_host_build_object_bvh    the OUTPUT CONTRACT of CreateBVH (RM:681-722): implicit heap, 2^D - 1 nodes; the pairing
+//                                heuristic of RM:510-678 depends on .NET's unstable List.Sort and is not reproducible
+//                                (SURVEY.md A.7), so the tree itself is built by a deterministic median split
+//
+// Arithmetic follows UnityEngine's float32 Vector3 helpers: separate multiplies and adds (no fma; this file is
+// compiled with -ffp-contract=off), left-to-right sums, Vector3.Normalize = v / sqrt(x*x + y*y + z*z) or zero when the
+// magnitude is <= 1e-5.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/urt.h"
+
+namespace {
+
+struct V3 { float x, y, z; };
+inline V3 sub(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 add(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }   // Vector3.Cross
+inline V3 normalize(V3 v) {                                                                                        // Vector3.Normalize
+  float mag = std::sqrt(v.x * v.x + v.y * v.y + v.z * v.z);
+  if (mag > 1e-5f) return {v.x / mag, v.y / mag, v.z / mag};
+  return {0.0f, 0.0f, 0.0f};
+}
+inline V3 ld(const float* p) { return {p[0], p[1], p[2]}; }
+
+struct Key {
+  uint32_t a, b, c;
+  bool operator==(const Key& o) const { return a == o.a && b == o.b && c == o.c; }
+};
+struct KeyHash {
+  size_t operator()(const Key& k) const {
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ k.a;
+    h = (h ^ (h >> 32)) * 0xBF58476D1CE4E5B9ull + k.b;
+    h = (h ^ (h >> 29)) * 0x94D049BB133111EBull + k.c;
+    return (size_t)(h ^ (h >> 31));
+  }
+};
+inline uint32_t bits_no_negzero(float f) {           // -0 == +0 for the reference's (a - b).sqrMagnitude test
+  uint32_t u; std::memcpy(&u, &f, 4);
+  return u == 0x80000000u ? 0u : u;
+}
+
+// MultiplyPoint3x4 on a Unity Matrix4x4 stored column-major (m[col*4+row]): rows evaluated left to right, mul then add
+inline V3 multiply_point_3x4(const float* m, V3 p) {
+  return {m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12],
+          m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
+          m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14]};
+}
+
+std::string g_host_error;
+int host_fail(int code, const std::string& msg) { g_host_error = msg; return code; }
+
+}  // namespace
+
+extern "C" {
+
+const char* urt_host_last_error(void) { return g_host_error.c_str(); }
+
+int urt_host_compute_normals(const float* vertices, int n_vertices, const int32_t* indices, int n_indices, float* out_normals) {
+  if (n_vertices < 0 || n_indices < 0 || n_indices % 3 != 0) return host_fail(URT_ERR_INVALID_ARGUMENT, "ComputeNormals: bad counts");
+  if ((n_vertices && (!vertices || !out_normals)) || (n_indices && !indices)) return host_fail(URT_ERR_INVALID_ARGUMENT, "ComputeNormals: NULL array");
+  try {
+    // weld: vertices whose positions are equal form one group (RM:351 with EPSILON = 3 * float.Epsilon: equality for
+    // anything but differences that underflow when squared)
+    std::unordered_map<Key, int, KeyHash> groups;
+    groups.reserve((size_t)n_vertices * 2);
+    std::vector<int> group_of((size_t)n_vertices);
+    for (int i = 0; i < n_vertices; i++) {
+      Key k{bits_no_negzero(vertices[3 * i]), bits_no_negzero(vertices[3 * i + 1]), bits_no_negzero(vertices[3 * i + 2])};
+      auto it = groups.find(k);
+      if (it == groups.end()) it = groups.emplace(k, (int)groups.size()).first;
+      group_of[(size_t)i] = it->second;
+    }
+    std::vector<V3> acc(groups.size(), V3{0, 0, 0});
+    // every index slot j (ascending, the order of the reference's LINQ query) adds the un-normalised normal of ITS
+    // triangle to the group of the vertex it refers to (RM:355-362)
+    for (int start = 0; start + 2 < n_indices; start += 3) {
+      int i0 = indices[start], i1 = indices[start + 1], i2 = indices[start + 2];
+      if (i0 < 0 || i0 >= n_vertices || i1 < 0 || i1 >= n_vertices || i2 < 0 || i2 >= n_vertices)
+        return host_fail(URT_ERR_SCENE, "ComputeNormals: index outside _Vertices");
+      V3 a = ld(vertices + 3 * i0), b = ld(vertices + 3 * i1), c = ld(vertices + 3 * i2);
+      V3 face = cross(sub(b, a), sub(c, a));
+      const int vs[3] = {i0, i1, i2};
+      for (int j = 0; j < 3; j++) { V3& s = acc[(size_t)group_of[(size_t)vs[j]]]; s = add(s, face); }
+    }
+    for (int i = 0; i < n_vertices; i++) {
+      V3 n = normalize(acc[(size_t)group_of[(size_t)i]]);
+      out_normals[3 * i] = n.x; out_normals[3 * i + 1] = n.y; out_normals[3 * i + 2] = n.z;
+    }
+    return URT_OK;
+  } catch (...) { return host_fail(URT_ERR_OUT_OF_MEMORY, "ComputeNormals: allocation failed"); }
+}
+
+int urt_host_mesh_leaf_bounds(const void* mesh_objects, int n_meshes, const float* vertices, int n_vertices, const int32_t* indices,
+                              int n_indices, int literal, urt_BVHNode* out_leaves) {
+  if (n_meshes < 0 || (n_meshes && (!mesh_objects || !out_leaves))) return host_fail(URT_ERR_INVALID_ARGUMENT, "SetupBVHLeaves: bad arguments");
+  for (int m = 0; m < n_meshes; m++) {
+    urt_MeshObject mo;
+    std::memcpy(&mo, (const uint8_t*)mesh_objects + (size_t)m * sizeof mo, sizeof mo);
+    long off = mo.indices_offset, cnt = mo.indices_count;
+    if (off < 0 || cnt < 0 || off + cnt > n_indices) return host_fail(URT_ERR_SCENE, "SetupBVHLeaves: MeshObject range outside _Indices");
+    auto point = [&](long slot, V3& out) -> bool {
+      int vi = indices[slot];
+      if (vi < 0 || vi >= n_vertices) return false;
+      out = multiply_point_3x4(mo.localToWorldMatrix, ld(vertices + 3 * (size_t)vi));
+      return true;
+    };
+    V3 lo, hi;
+    long first;
+    if (literal) {
+      // RM:415-416: starts from _vertices[_indices[0]] — the GLOBAL first index, through THIS mesh's matrix — and
+      // RM:421: refines from offset + 1, so the mesh's own first index slot is skipped (A.7)
+      if (n_indices <= 0 || !point(0, lo)) return host_fail(URT_ERR_SCENE, "SetupBVHLeaves: _Indices[0] invalid");
+      hi = lo;
+      first = off + 1;
+    } else {
+      if (cnt == 0) { std::memset(&out_leaves[m], 0, sizeof(urt_BVHNode)); out_leaves[m].index = m; continue; }
+      if (!point(off, lo)) return host_fail(URT_ERR_SCENE, "SetupBVHLeaves: index outside _Vertices");
+      hi = lo;
+      first = off + 1;
+    }
+    for (long i = first; i < off + cnt; i++) {
+      V3 t;
+      if (!point(i, t)) return host_fail(URT_ERR_SCENE, "SetupBVHLeaves: index outside _Vertices");
+      lo = {std::min(lo.x, t.x), std::min(lo.y, t.y), std::min(lo.z, t.z)};      // Mathf.Min / Mathf.Max
+      hi = {std::max(hi.x, t.x), std::max(hi.y, t.y), std::max(hi.z, t.z)};
+    }
+    out_leaves[m].vmin[0] = lo.x; out_leaves[m].vmin[1] = lo.y; out_leaves[m].vmin[2] = lo.z;
+    out_leaves[m].vmax[0] = hi.x; out_leaves[m].vmax[1] = hi.y; out_leaves[m].vmax[2] = hi.z;
+    out_leaves[m].index = m;                                                     // RM:417
+  }
+  return URT_OK;
+}
+
+int urt_host_sphere_leaf_bounds(const void* spheres, int n_spheres, int literal, urt_BVHNode* out_leaves) {
+  if (n_spheres < 0 || (n_spheres && (!spheres || !out_leaves))) return host_fail(URT_ERR_INVALID_ARGUMENT, "SetupBVHLeaves: bad arguments");
+  for (int i = 0; i < n_spheres; i++) {
+    urt_Sphere s;
+    std::memcpy(&s, (const uint8_t*)spheres + (size_t)i * sizeof s, sizeof s);
+    // RM:445-446: vmin = position - (-r,-r,-r), vmax = position - (r,r,r): INVERTED; harmless for the slab test and the unions
+    float a[3], b[3];
+    for (int k = 0; k < 3; k++) { a[k] = s.position[k] - (-s.radius); b[k] = s.position[k] - s.radius; }
+    for (int k = 0; k < 3; k++) {
+      out_leaves[i].vmin[k] = literal ? a[k] : std::min(a[k], b[k]);
+      out_leaves[i].vmax[k] = literal ? b[k] : std::max(a[k], b[k]);
+    }
+    out_leaves[i].index = i;
+  }
+  return URT_OK;
+}
+
+int urt_host_object_bvh_length(int n_objects) {       // RM:683,705: depth = ceil(log2 n) + 1, length 2^depth - 1
+  if (n_objects <= 0) return 0;
+  int depth = 1;
+  while ((1 << (depth - 1)) < n_objects) depth++;
+  return (1 << depth) - 1;
+}
+
+int urt_host_build_object_bvh(const urt_BVHNode* leaves, int n_objects, urt_BVHNode* out_nodes, int capacity) {
+  int len = urt_host_object_bvh_length(n_objects);
+  if (n_objects < 0 || (n_objects && (!leaves || !out_nodes)) || capacity < len) return host_fail(URT_ERR_INVALID_ARGUMENT, "CreateBVH: bad arguments");
+  try {
+    for (int i = 0; i < len; i++) { std::memset(&out_nodes[i], 0, sizeof(urt_BVHNode)); out_nodes[i].index = -1; }   // filler (RM:490-494)
+    if (n_objects == 0) return URT_OK;
+    struct Item { float c[3]; int leaf; };
+    std::vector<Item> items((size_t)n_objects);
+    for (int i = 0; i < n_objects; i++) {
+      for (int k = 0; k < 3; k++) items[(size_t)i].c[k] = 0.5f * leaves[i].vmin[k] + 0.5f * leaves[i].vmax[k];
+      items[(size_t)i].leaf = i;
+    }
+    struct Job { int slot, lo, hi; };
+    std::vector<Job> jobs{{0, 0, n_objects}};
+    while (!jobs.empty()) {
+      Job j = jobs.back(); jobs.pop_back();
+      urt_BVHNode& nd = out_nodes[j.slot];
+      float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, clo[3], chi[3];
+      std::memcpy(clo, lo, sizeof lo); std::memcpy(chi, hi, sizeof hi);
+      for (int q = j.lo; q < j.hi; q++) {
+        const urt_BVHNode& lf = leaves[items[(size_t)q].leaf];
+        for (int k = 0; k < 3; k++) {
+          // union over min/max of both corners, as the reference's parent boxes do (RM:642-647)
+          lo[k] = std::min(lo[k], std::min(lf.vmin[k], lf.vmax[k]));
+          hi[k] = std::max(hi[k], std::max(lf.vmin[k], lf.vmax[k]));
+          clo[k] = std::min(clo[k], items[(size_t)q].c[k]); chi[k] = std::max(chi[k], items[(size_t)q].c[k]);
+        }
+      }
+      if (j.hi - j.lo == 1) { nd = leaves[items[(size_t)j.lo].leaf]; continue; }      // a leaf keeps its own (possibly inverted) box and index
+      for (int k = 0; k < 3; k++) { nd.vmin[k] = lo[k]; nd.vmax[k] = hi[k]; }
+      nd.index = -1;
+      int ax = 0;
+      if (chi[1] - clo[1] > chi[ax] - clo[ax]) ax = 1;
+      if (chi[2] - clo[2] > chi[ax] - clo[ax]) ax = 2;
+      std::sort(items.begin() + j.lo, items.begin() + j.hi, [ax](const Item& a, const Item& b) {
+        return a.c[ax] < b.c[ax] || (a.c[ax] == b.c[ax] && a.leaf < b.leaf);
+      });
+      int half = (j.hi - j.lo + 1) / 2;
+      jobs.push_back({2 * j.slot + 1, j.lo, j.lo + half});
+      jobs.push_back({2 * j.slot + 2, j.lo + half, j.hi});
+    }
+    return URT_OK;
+  } catch (...) { return host_fail(URT_ERR_OUT_OF_MEMORY, "CreateBVH: allocation failed"); }
+}
+
+}  // extern "C"

@@ -20,8 +20,26 @@ import math
 
 import numpy as np
 
-from . import scenes
+from dataclasses import dataclass, field
+
+from . import host_scene, scenes
 from .unity_api import ComputeBuffer, ComputeShader, Context, Graphics, Material, RenderTexture
+
+
+@dataclass
+class RayTraceObject:
+    """Assets/Scripts/RayTraceObject.cs: what a scene object contributes (RO:9-19).  type 1 = analytic sphere
+    (position, radius), anything else = mesh (vertices, triangles of submesh 0, localToWorldMatrix)."""
+    type: int = 0
+    albedoColor: tuple = (0.0, 0.4, 1.0)          # RO:12
+    specularColor: tuple = (0.7, 0.0, 1.0)        # RO:13
+    emissionColor: tuple = (0.0, 0.0, 0.0)        # RO:14
+    smoothness: float = 0.69                      # RO:15
+    position: tuple = (0.0, 0.0, 0.0)             # RO:34 (spheres)
+    radius: float = 0.5                           # RO:33 (spheres)
+    vertices: np.ndarray = field(default_factory=lambda: np.zeros((0, 3), np.float32))      # mesh.vertices
+    triangles: np.ndarray = field(default_factory=lambda: np.zeros((0, 3), np.int32))       # mesh.GetIndices(0)
+    localToWorldMatrix: np.ndarray = field(default_factory=lambda: scenes.trs())            # transform.localToWorldMatrix
 
 
 class RayTraceMaster:
@@ -43,10 +61,53 @@ class RayTraceMaster:
         self._converged = None                       # RM:12
         self._additionMaterial = None                # RM:20
         self._treesNeedRebuilding = True             # RM:24
+        self._rayTraceObjects = []                   # RM:22 (empty: the scene arrives pre-flattened in `scene`)
         self.SkyboxTexture = None                    # RM:10
         self._meshObjectBuffer = self._vertexBuffer = self._indexBuffer = self._normalBuffer = None
         self._sphereBuffer = self._meshObjectBVHBuffer = self._sphereBVHBuffer = None
         self.screen_width, self.screen_height = scene.width, scene.height
+
+    # RM:215-230
+    def RegisterObject(self, obj: RayTraceObject):
+        self._rayTraceObjects.append(obj)
+        self._treesNeedRebuilding = True
+
+    def UnregisterObject(self, obj: RayTraceObject):
+        self._rayTraceObjects.remove(obj)
+        self._treesNeedRebuilding = True
+
+    # RM:262-336 — flatten the registered objects into the lists the buffers are made from; normals (RM:340-368) and the
+    # object-level BVHs (RM:405-722 output contract) come from the C++ host library (csrc/host_scene.cpp)
+    def RebuildObjectLists(self, literal_leaf_bounds: bool = False):
+        s = self.scene
+        spheres, mesh_objects, verts, idx = [], [], [], []
+        nv = ni = 0
+        for obj in self._rayTraceObjects:
+            lighting = scenes._params(obj.albedoColor, obj.specularColor, obj.emissionColor, obj.smoothness)
+            if obj.type == 1:                                                     # RM:277-293
+                sp = np.zeros((), scenes.SPHERE_DT)
+                sp["position"], sp["radius"], sp["lighting"] = obj.position, obj.radius, lighting
+                spheres.append(sp)
+            else:                                                                 # RM:295-321
+                v = np.asarray(obj.vertices, np.float32).reshape(-1, 3)
+                t = np.asarray(obj.triangles, np.int32).reshape(-1)
+                mo = np.zeros((), scenes.MESHOBJECT_DT)
+                mo["localToWorldMatrix"], mo["indices_offset"], mo["indices_count"], mo["lighting"] = obj.localToWorldMatrix, ni, len(t), lighting
+                verts.append(v)
+                idx.append(t + nv)                                                # RM:305: offset by the first vertex
+                mesh_objects.append(mo)
+                nv += len(v)
+                ni += len(t)
+        s.spheres = np.array(spheres, scenes.SPHERE_DT) if spheres else np.zeros(0, scenes.SPHERE_DT)
+        s.mesh_objects = np.array(mesh_objects, scenes.MESHOBJECT_DT) if mesh_objects else np.zeros(0, scenes.MESHOBJECT_DT)
+        s.vertices = np.concatenate(verts) if verts else np.zeros((0, 3), np.float32)
+        s.indices = np.concatenate(idx).astype(np.int32) if idx else np.zeros(0, np.int32)
+        s.normals = host_scene.compute_normals(s.vertices, s.indices)            # RM:328
+        # CreateBVH(_meshObjects) / CreateBVH(_spheres), RM:727-728 (the reference throws on an empty list, A.7; here empty = no buffer)
+        s.mesh_bvh = host_scene.build_object_bvh(host_scene.mesh_leaf_bounds(s.mesh_objects, s.vertices, s.indices, literal_leaf_bounds)) \
+            if len(s.mesh_objects) else np.zeros(0, scenes.BVHNODE_DT)
+        s.sphere_bvh = host_scene.build_object_bvh(host_scene.sphere_leaf_bounds(s.spheres, literal_leaf_bounds)) \
+            if len(s.spheres) else np.zeros(0, scenes.BVHNODE_DT)
 
     # RM:233-252
     def CreateComputeBuffer(self, buffer, data: np.ndarray, stride: int):
@@ -135,6 +196,8 @@ class RayTraceMaster:
         if self._treesNeedRebuilding:
             self._currentSample = 0
             self._treesNeedRebuilding = False
+            if self._rayTraceObjects:
+                self.RebuildObjectLists()
             self.RebuildTrees()
         self.SetShaderParameters()
         self.Render(destination)
