@@ -1,0 +1,152 @@
+"""GPU: behaviour of the C ABI at the boundary (include/urt.h) — error codes, Unity-like leniency, edge cases of the
+dispatch (empty scene, zero loops, partial dispatch, buffer re-upload), all through the Python mirror of the reference's calls."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle
+from unityraytracer_amd import ComputeBuffer, ComputeShader, Graphics, Material, RayTraceMaster, RenderTexture, UrtError, scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def bits_equal(a, b):
+    return np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_error_codes_and_unity_leniency(gpu_ctx):
+    sh = ComputeShader(gpu_ctx)
+    b = ComputeBuffer(gpu_ctx, 4, 12)
+    with pytest.raises(UrtError) as e:
+        sh.SetBuffer(0, "_Spheres", b)                       # stride 12 != 56 (RM:744)
+    assert e.value.code == 6
+    with pytest.raises(UrtError) as e:
+        sh.SetBuffer(0, "_NoSuchBuffer", b)
+    assert e.value.code == 1
+    with pytest.raises(UrtError):
+        ComputeBuffer(gpu_ctx, 0, 12)                        # Unity: count must be > 0
+    with pytest.raises(UrtError):
+        ComputeBuffer(gpu_ctx, 4, 10)                        # stride must be a multiple of 4
+    with pytest.raises(UrtError) as e:
+        b.SetData(np.zeros(5 * 3, np.float32))               # more elements than the buffer holds
+    assert e.value.code == 1
+    sh.SetInt("_MeshBVH_len", 123)                           # static const in the shader: accepted, ignored (RS:73-74)
+    sh.SetInt("_SphereBVH_len", 7)
+    sh.SetFloat("_NotAUniform", 1.0)                         # Unity ignores undeclared names
+    sh.SetVector("_AlsoNot", (1, 2, 3, 4))
+    b.Release()
+    with pytest.raises(UrtError) as e:
+        gpu_ctx.check(gpu_ctx.lib.urt_buffer_release(gpu_ctx._h, 987654321))
+    assert e.value.code == 2
+    sh.SetTexture(0, "Result", None)
+    with pytest.raises(UrtError) as e:
+        sh.Dispatch(0, 1, 1, 1)                              # no Result bound
+    assert e.value.code == 5
+    with pytest.raises(UrtError):
+        sh.Dispatch(1, 1, 1, 1)                              # only kernel 0 exists
+    a, c = RenderTexture(gpu_ctx, 8, 8), RenderTexture(gpu_ctx, 16, 8)
+    with pytest.raises(UrtError):
+        Graphics.Blit(a, c)                                  # size mismatch
+    a.Release(); c.Release()
+
+
+def test_empty_scene_and_zero_loops(gpu_ctx):
+    """No buffers bound at all: ground plane + sky only (RS:375-379 treat missing buffers as count 0)."""
+    sc = scenes.Scene("empty", 100, 60, 3, 2, sky=scenes.make_sky(64, 32))
+    ref = pyoracle.Oracle(sc).render(threads=4)
+    for mode in (0, 1, 2, 3):
+        gpu_ctx.set_option("kernel_mode", mode)
+        m = RayTraceMaster(gpu_ctx, sc)
+        m.OnRenderImage()
+        assert bits_equal(m._target.GetPixels(), ref), mode
+        m.OnDisable()
+    # numBounces = 0: the bounce loop never runs -> (0,0,0,1); numRays = 0: 0/0 = NaN in rgb, alpha 1 (RS:444-468 literally)
+    sc0 = scenes.Scene("zero-bounces", 40, 24, 0, 1, sky=scenes.make_sky(64, 32))
+    m = RayTraceMaster(gpu_ctx, sc0); m.OnRenderImage(); img = m._target.GetPixels(); m.OnDisable()
+    assert bits_equal(img, pyoracle.Oracle(sc0).render()) and (img[..., :3] == 0).all() and (img[..., 3] == 1).all()
+    sc1 = scenes.Scene("zero-rays", 40, 24, 2, 0, sky=scenes.make_sky(64, 32))
+    m = RayTraceMaster(gpu_ctx, sc1); m.OnRenderImage(); img = m._target.GetPixels(); m.OnDisable()
+    assert np.isnan(img[..., :3]).all() and (img[..., 3] == 1).all()
+
+
+def test_partial_dispatch_writes_only_its_groups(gpu_ctx):
+    sc = scenes.mixed_test_scene(96, 64)
+    full = pyoracle.Oracle(sc)
+    full.build_own_blas()
+    ref = full.render(mode=1, threads=8)
+    m = RayTraceMaster(gpu_ctx, sc)
+    m.RebuildTrees(); m._treesNeedRebuilding = False
+    m.SetShaderParameters()
+    m.InitRenderTexture()
+    m.RayTraceShader.SetTexture(0, "Result", m._target)
+    m.RayTraceShader.Dispatch(0, 5, 3, 1)                    # 40 x 24 pixels of the 96 x 64 frame
+    img = m._target.GetPixels()
+    assert bits_equal(img[:24, :40], ref[:24, :40])
+    assert not img[24:].any() and not img[:, 40:].any()      # threads outside the dispatched groups wrote nothing
+    m.RayTraceShader.Dispatch(0, 1000, 1000, 1)              # more groups than pixels: clipped to the texture (RS:468)
+    assert bits_equal(m._target.GetPixels(), ref)
+    m.OnDisable()
+
+
+def test_setdata_after_bind_is_picked_up(gpu_ctx):
+    """SetData on a bound buffer (RM:250 runs every rebuild) must invalidate the derived device scene."""
+    sc = scenes.config1(96, 96, sky=scenes.make_sky(64, 32))
+    m = RayTraceMaster(gpu_ctx, sc)
+    m.OnRenderImage()
+    before = m._target.GetPixels()
+    moved = sc.spheres.copy()
+    moved["position"][:, 1] += 1.5
+    sc.spheres = moved
+    sc.sphere_bvh = scenes.build_object_bvh(*scenes.sphere_bounds(moved))
+    m._sphereBuffer.SetData(moved)                           # same ComputeBuffer objects, new contents
+    m._sphereBVHBuffer.SetData(sc.sphere_bvh)
+    m._frame = 0; m._currentSample = 0
+    m.OnRenderImage()
+    after = m._target.GetPixels()
+    assert not bits_equal(before, after)
+    assert bits_equal(after, pyoracle.Oracle(sc).render(threads=4))
+    m.OnDisable()
+
+
+def test_resize_resets_accumulation_and_external_texture(gpu_ctx):
+    sc = scenes.mixed_test_scene(64, 40)
+    m = RayTraceMaster(gpu_ctx, sc)
+    m.OnRenderImage(); m.OnRenderImage()
+    assert m._currentSample == 2
+    m.screen_width, m.screen_height = 48, 32                 # Screen resized: RM:826-845 recreate the targets, reset the sample
+    m.scene = sc.resized(48, 32)
+    m.OnRenderImage()
+    assert m._currentSample == 1 and m._target.width == 48
+    m.OnDisable()
+    # a RenderTexture over caller-owned device memory (what the multi-GPU gather uses): here the "caller" memory is another
+    # texture's storage (torch is deliberately not imported here: two HIP runtimes initialised in the wrong order in one
+    # process do not share the GPU; bench.py imports torch first)
+    owner = RenderTexture(gpu_ctx, 64, 40)
+    ext = RenderTexture(gpu_ctx, 64, 40, external_ptr=owner.device_ptr())
+    m2 = RayTraceMaster(gpu_ctx, sc)
+    m2.OnRenderImage()
+    Graphics.Blit(m2._target, ext)
+    assert bits_equal(owner.GetPixels(), m2._target.GetPixels())
+    ext.Release()                                            # releasing the alias does not free caller-owned memory
+    assert bits_equal(owner.GetPixels(), m2._target.GetPixels())
+    owner.Release()
+    m2.OnDisable()
+
+
+def test_counters_and_watchdog(gpu_ctx):
+    sc = scenes.mixed_test_scene(64, 40)
+    gpu_ctx.set_option("kernel_mode", 3); gpu_ctx.set_option("count_stats", 1); gpu_ctx.set_option("time_dispatch", 1)
+    gpu_ctx.reset_counters()
+    m = RayTraceMaster(gpu_ctx, sc)
+    for _ in range(3):
+        m.OnRenderImage()
+    c = gpu_ctx.counters()
+    assert c["dispatches"] == 3 and c["pixels"] == 3 * 64 * 40 and c["rays"] >= c["pixels"] and c["trace_ms"] > 0
+    assert c["hit_sky"] + c["hit_ground"] + c["hit_sphere"] + c["hit_tri"] == c["rays"] and c["watchdog_trips"] == 0
+    gpu_ctx.reset_counters()
+    assert gpu_ctx.counters()["rays"] == 0
+    gpu_ctx.set_option("count_stats", 0); gpu_ctx.set_option("time_dispatch", 0)
+    with pytest.raises(UrtError):
+        gpu_ctx.set_option("kernel_mode", 9)
+    with pytest.raises(UrtError):
+        gpu_ctx.set_option("no_such_option", 1)
+    m.OnDisable()
