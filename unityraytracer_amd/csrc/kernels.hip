@@ -106,59 +106,76 @@ __device__ __forceinline__ void test_leaf(const DevScene& S, int32_t leaf, v3 o,
 // ---------------------------------------------------------------------------------------------------
 // triangle BVH traversal for one MeshObject.  Replaces the brute-force loop RS:243-266 and returns
 // the same winner: minimum t, ties inside one call going to the lowest index slot (A.4).
-// Stack: LDS, entry e of this lane at stk[e * 64].
+// Stack: LDS, entry e of this lane at stk[e * 64].  Cursor values: >= 0 interior node, < 0 leaf code,
+// kBlasDone = traversal finished.
 // ---------------------------------------------------------------------------------------------------
+static constexpr int32_t kBlasDone = (int32_t)0x80000000;   // never a valid leaf code (it would be ~0x7fffffff)
+
+struct BlasRay { v3 idir, nop, nom; };   // per-ray slab constants: t = fma(bound, idir, nop|nom)
+
+// boxes are widened per ray by pad = 2^-16 * max|origin| on top of the build-time pad (DESIGN.md "BLAS traversal")
+__device__ __forceinline__ BlasRay blas_ray(v3 o, v3 d) {
+  BlasRay R;
+  float pad = f_max(f_max(f_abs(o.x), f_abs(o.y)), f_abs(o.z)) * 1.52587890625e-5f;
+  R.idir = mk3(blas_rcp(d.x), blas_rcp(d.y), blas_rcp(d.z));
+  R.nop = mk3(-((o.x + pad) * R.idir.x), -((o.y + pad) * R.idir.y), -((o.z + pad) * R.idir.z));
+  R.nom = mk3(-((o.x - pad) * R.idir.x), -((o.y - pad) * R.idir.y), -((o.z - pad) * R.idir.z));
+  return R;
+}
+
+__device__ __forceinline__ int32_t blas_pop(int* stk, int& sp) {
+  if (sp == 0) return kBlasDone;
+  sp--;
+  return stk[sp * 64];
+}
+
+// One interior-node step: slab-test both children against [0, tbest], descend into the nearer hit child (ties: child 0),
+// push the other; returns the next cursor.
+template <bool COUNT>
+__device__ __forceinline__ int32_t blas_node_step(const DevScene& S, int32_t cur, const BlasRay& R, float tbest, int* stk, int& sp,
+                                                  LocalCounters& lc) {
+  if (COUNT) lc.blas_nodes++;
+  const float4* n = S.blas_nodes + 4 * (size_t)cur;
+  float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
+  // child 0: min (q0.x q0.y q0.z) max (q0.w q1.x q1.y)
+  float a1x = f_fma(q0.x, R.idir.x, R.nop.x), a2x = f_fma(q0.w, R.idir.x, R.nom.x);
+  float a1y = f_fma(q0.y, R.idir.y, R.nop.y), a2y = f_fma(q1.x, R.idir.y, R.nom.y);
+  float a1z = f_fma(q0.z, R.idir.z, R.nop.z), a2z = f_fma(q1.y, R.idir.z, R.nom.z);
+  float tn0 = f_max(f_max(f_min(a1x, a2x), f_min(a1y, a2y)), f_max(f_min(a1z, a2z), 0.0f));
+  float tf0 = f_min(f_min(f_max(a1x, a2x), f_max(a1y, a2y)), f_min(f_max(a1z, a2z), tbest));
+  // child 1: min (q1.z q1.w q2.x) max (q2.y q2.z q2.w)
+  float b1x = f_fma(q1.z, R.idir.x, R.nop.x), b2x = f_fma(q2.y, R.idir.x, R.nom.x);
+  float b1y = f_fma(q1.w, R.idir.y, R.nop.y), b2y = f_fma(q2.z, R.idir.y, R.nom.y);
+  float b1z = f_fma(q2.x, R.idir.z, R.nop.z), b2z = f_fma(q2.w, R.idir.z, R.nom.z);
+  float tn1 = f_max(f_max(f_min(b1x, b2x), f_min(b1y, b2y)), f_max(f_min(b1z, b2z), 0.0f));
+  float tf1 = f_min(f_min(f_max(b1x, b2x), f_max(b1y, b2y)), f_min(f_max(b1z, b2z), tbest));
+  bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
+  int32_t c0 = as_int(q3.x), c1 = as_int(q3.y);
+  if (h0 && h1) {
+    bool swap = tn1 < tn0;
+    stk[sp * 64] = swap ? c0 : c1;
+    sp++;
+    return swap ? c1 : c0;
+  }
+  if (h0) return c0;
+  if (h1) return c1;
+  return blas_pop(stk, sp);
+}
+
 template <bool COUNT>
 __device__ __forceinline__ void intersect_mesh(const DevScene& S, int32_t root, v3 o, v3 d, HitRec& best,
                                                int* stk, LocalCounters& lc) {
   if (root == kEmptyMeshRoot) return;
-  // per-ray slab constants: boxes are widened by pad = 2^-16 * max|origin| on top of the build-time pad
-  float pad = f_max(f_max(f_abs(o.x), f_abs(o.y)), f_abs(o.z)) * 1.52587890625e-5f;
-  v3 idir = mk3(blas_rcp(d.x), blas_rcp(d.y), blas_rcp(d.z));
-  v3 nop = mk3(-((o.x + pad) * idir.x), -((o.y + pad) * idir.y), -((o.z + pad) * idir.z));
-  v3 nom = mk3(-((o.x - pad) * idir.x), -((o.y - pad) * idir.y), -((o.z - pad) * idir.z));
+  BlasRay R = blas_ray(o, d);
   int best_i = -1;          // index slot of a hit made in THIS call (enables the equal-t tie rule)
   int sp = 0;
   int32_t cur = root;
-  for (;;) {
+  while (cur != kBlasDone) {
     if (cur >= 0) {
-      if (COUNT) lc.blas_nodes++;
-      const float4* n = S.blas_nodes + 4 * (size_t)cur;
-      float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
-      float tb = best.t;
-      // child 0: min (q0.x q0.y q0.z) max (q0.w q1.x q1.y)
-      float a1x = f_fma(q0.x, idir.x, nop.x), a2x = f_fma(q0.w, idir.x, nom.x);
-      float a1y = f_fma(q0.y, idir.y, nop.y), a2y = f_fma(q1.x, idir.y, nom.y);
-      float a1z = f_fma(q0.z, idir.z, nop.z), a2z = f_fma(q1.y, idir.z, nom.z);
-      float tn0 = f_max(f_max(f_min(a1x, a2x), f_min(a1y, a2y)), f_max(f_min(a1z, a2z), 0.0f));
-      float tf0 = f_min(f_min(f_max(a1x, a2x), f_max(a1y, a2y)), f_min(f_max(a1z, a2z), tb));
-      // child 1: min (q1.z q1.w q2.x) max (q2.y q2.z q2.w)
-      float b1x = f_fma(q1.z, idir.x, nop.x), b2x = f_fma(q2.y, idir.x, nom.x);
-      float b1y = f_fma(q1.w, idir.y, nop.y), b2y = f_fma(q2.z, idir.y, nom.y);
-      float b1z = f_fma(q2.x, idir.z, nop.z), b2z = f_fma(q2.w, idir.z, nom.z);
-      float tn1 = f_max(f_max(f_min(b1x, b2x), f_min(b1y, b2y)), f_max(f_min(b1z, b2z), 0.0f));
-      float tf1 = f_min(f_min(f_max(b1x, b2x), f_max(b1y, b2y)), f_min(f_max(b1z, b2z), tb));
-      bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
-      int32_t c0 = as_int(q3.x), c1 = as_int(q3.y);
-      if (h0 && h1) {
-        bool swap = tn1 < tn0;
-        stk[sp * 64] = swap ? c0 : c1;
-        sp++;
-        cur = swap ? c1 : c0;
-      } else if (h0) {
-        cur = c0;
-      } else if (h1) {
-        cur = c1;
-      } else {
-        if (sp == 0) break;
-        sp--;
-        cur = stk[sp * 64];
-      }
+      cur = blas_node_step<COUNT>(S, cur, R, best.t, stk, sp, lc);
     } else {
       test_leaf<COUNT>(S, cur, o, d, best, best_i, lc);
-      if (sp == 0) break;
-      sp--;
-      cur = stk[sp * 64];
+      cur = blas_pop(stk, sp);
     }
   }
 }
@@ -447,6 +464,29 @@ __global__ __launch_bounds__(256) void k_mega(DevScene S, FrameParams P, float4*
   flush_counters<COUNT>(lc, ctr);
 }
 
+// Work distribution of the persistent kernels: slot idx of the frame (tile order: 64 consecutive slots = one 8x8 tile)
+// -> pixel; false for slots that fall outside the dispatched region (ragged right/top edge).
+__device__ __forceinline__ bool slot_pixel(const FrameParams& P, unsigned int idx, int& x, int& y) {
+  int tile = (int)(idx >> 6), l = (int)(idx & 63u);
+  int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
+  x = tx * 8 + (l & 7);
+  y = (P.first_group_row + ty * P.row_stride) * 8 + (l >> 3);
+  return x < P.region_w && y < P.region_h;
+}
+
+// The wave takes popcount(want) slots from the frame's work counter with ONE atomic; each lane of `want` gets its own slot
+// (prefix popcount).  Returns the slot or 0xffffffff; sets `exhausted` once the counter has passed `total`.
+__device__ __forceinline__ unsigned int wave_fetch_slots(unsigned long long want, bool mine, unsigned int* next, unsigned int total, bool& exhausted) {
+  const int lane = threadIdx.x & 63;
+  unsigned int n = (unsigned int)__popcll(want);
+  unsigned int base = 0;
+  if (lane == 0) base = atomicAdd(next, n);
+  base = __shfl(base, 0, 64);
+  if (base + n >= total) exhausted = true;
+  unsigned int idx = base + (unsigned int)__popcll(want & ((1ull << lane) - 1ull));
+  return (mine && idx < total) ? idx : 0xffffffffu;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // mode 2 (default): persistent waves with path regeneration.
 // A fixed grid of waves stays resident for the whole frame.  Every lane owns one path at a time; when
@@ -463,8 +503,6 @@ __global__ __launch_bounds__(256) void k_persist(DevScene S, FrameParams P, floa
   int *tl, *bl;
   lane_stacks(P, tl, bl);
   LocalCounters lc;
-  const int lane = threadIdx.x & 63;
-  const unsigned long long lt_mask = (1ull << lane) - 1ull;
   const unsigned int total = (unsigned int)(P.tiles_x * P.n_strips) * 64u;
   bool alive = false, exhausted = false;
 #ifdef URT_STAMPS
@@ -477,28 +515,16 @@ __global__ __launch_bounds__(256) void k_persist(DevScene S, FrameParams P, floa
     unsigned long long dead = __ballot(!alive);
     int ndead = __popcll(dead);
     if (!exhausted && ndead >= P.refill_min) {
-      unsigned int base = 0;
-      if (lane == 0) base = atomicAdd(next, (unsigned int)ndead);
-      base = __shfl(base, 0, 64);
-      if (base + (unsigned int)ndead >= total) exhausted = true;
+      unsigned int idx = wave_fetch_slots(dead, !alive, next, total, exhausted);
 #ifdef URT_STAMPS
       n_fetch++; if (exhausted && !t_exh) t_exh = wall_clock64();
 #endif
-      if (!alive) {
-        unsigned int idx = base + (unsigned int)__popcll(dead & lt_mask);
-        if (idx < total) {
-          int tile = (int)(idx >> 6), l = (int)(idx & 63u);
-          int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
-          x = tx * 8 + (l & 7);
-          y = (P.first_group_row + ty * P.row_stride) * 8 + (l >> 3);
-          if (x < P.region_w && y < P.region_h) {
-            alive = true;
-            px = (float)x; py = (float)y;
-            seed = P.seed; ray_i = 0; k = 0;
-            avg = mk3(0, 0, 0); res = mk3(0, 0, 0); energy = mk3(1, 1, 1);
-            camera_ray<kPOffAfterScene>(P, x, y, seed, o, d);
-          }
-        }
+      if (idx != 0xffffffffu && slot_pixel(P, idx, x, y)) {
+        alive = true;
+        px = (float)x; py = (float)y;
+        seed = P.seed; ray_i = 0; k = 0;
+        avg = mk3(0, 0, 0); res = mk3(0, 0, 0); energy = mk3(1, 1, 1);
+        camera_ray<kPOffAfterScene>(P, x, y, seed, o, d);
       }
     }
     if (__ballot(alive) == 0) {
@@ -527,7 +553,7 @@ __global__ __launch_bounds__(256) void k_persist(DevScene S, FrameParams P, floa
     }
   }
 #ifdef URT_STAMPS
-  if (lane == 0) {
+  if ((threadIdx.x & 63) == 0) {
     unsigned long long* st = (unsigned long long*)(next + 16);
     size_t w = ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 4;
     st[w] = t_start; st[w + 1] = t_exh; st[w + 2] = wall_clock64(); st[w + 3] = ((unsigned long long)n_iter << 32) | n_fetch;
@@ -551,7 +577,6 @@ __global__ __launch_bounds__(256) void k_persist(DevScene S, FrameParams P, floa
 // executes them changes, so pixels are bit-identical.
 // ---------------------------------------------------------------------------------------------------
 enum : int { ST_DEAD = 0, ST_FRONT = 1, ST_RESUME = 2, ST_BLAS = 3, ST_SHADE = 4 };
-static constexpr int32_t kBlasDone = (int32_t)0x80000000;   // never a valid leaf code (~0x7fffffff)
 static constexpr unsigned int kWatchdogIters = 1u << 24;    // scheduler trips per wave (a frame needs ~1e3-1e5)
 static constexpr unsigned int kWatchdogSteps = 1u << 24;    // traversal steps per scheduled BLAS phase
 
@@ -561,8 +586,6 @@ __global__ __launch_bounds__(256) void k_sched(DevScene S, FrameParams P, float4
   int *tl, *bl;
   lane_stacks(P, tl, bl);
   LocalCounters lc;
-  const int lane = threadIdx.x & 63;
-  const unsigned long long lt_mask = (1ull << lane) - 1ull;
   const unsigned int total = (unsigned int)(P.tiles_x * P.n_strips) * 64u;
   bool exhausted = false;
   int st = ST_DEAD;
@@ -581,65 +604,32 @@ __global__ __launch_bounds__(256) void k_sched(DevScene S, FrameParams P, float4
     if (watchdog) break;
     unsigned long long mD = __ballot(st == ST_DEAD);
     int nD = __popcll(mD);
-    // ---- refill dead lanes from the frame's work counter (one atomic per refill) ----
-    if (!exhausted && nD >= P.refill_min) {
-      unsigned int base = 0;
-      if (lane == 0) base = atomicAdd(next, (unsigned int)nD);
-      base = __shfl(base, 0, 64);
-      if (base + (unsigned int)nD >= total) exhausted = true;
-      if (st == ST_DEAD) {
-        unsigned int idx = base + (unsigned int)__popcll(mD & lt_mask);
-        if (idx < total) {
-          int tile = (int)(idx >> 6), l = (int)(idx & 63u);
-          int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
-          x = tx * 8 + (l & 7);
-          y = (P.first_group_row + ty * P.row_stride) * 8 + (l >> 3);
-          if (x < P.region_w && y < P.region_h) {
-            st = ST_FRONT;
-            seed = P.seed; ray_i = 0; k = 0;
-            avg = mk3(0, 0, 0); res = mk3(0, 0, 0); energy = mk3(1, 1, 1);
-            camera_ray<kPOffAfterScene>(P, x, y, seed, o, d);
-          }
-        }
-      }
-    }
     int nB = __popcll(__ballot(st == ST_BLAS));
     int nS = __popcll(__ballot(st == ST_SHADE));
     int nF = __popcll(__ballot(st == ST_FRONT || st == ST_RESUME));
-    nD = __popcll(__ballot(st == ST_DEAD));
+    // ---- refill dead lanes from the frame's work counter (one atomic per refill): when enough lanes are dead, or when
+    // nothing else is left to run ----
+    if (!exhausted && nD > 0 && (nD >= P.refill_min || nB + nS + nF == 0)) {
+      unsigned int idx = wave_fetch_slots(mD, st == ST_DEAD, next, total, exhausted);
+      if (idx != 0xffffffffu && slot_pixel(P, idx, x, y)) {
+        st = ST_FRONT;
+        seed = P.seed; ray_i = 0; k = 0;
+        avg = mk3(0, 0, 0); res = mk3(0, 0, 0); energy = mk3(1, 1, 1);
+        camera_ray<kPOffAfterScene>(P, x, y, seed, o, d);
+      }
+      nF = __popcll(__ballot(st == ST_FRONT || st == ST_RESUME));
+      nD = __popcll(__ballot(st == ST_DEAD));
+    }
     bool can_refill = !exhausted && nD >= P.refill_min;
     if (++wave_iters > kWatchdogIters) { watchdog = true; break; }   // an exit every wave reaches, whatever the data
     int phase;
     int exit_below = 1;              // traversal runs to completion unless other lanes can make progress meanwhile
-    if (nB >= P.blas_min) { phase = ST_BLAS; if (nS + nF > 0 || can_refill) exit_below = P.blas_exit; }
+    if (nB >= P.blas_min) { phase = ST_BLAS; if (nS + nF > 0 || can_refill) exit_below = min(P.blas_exit, nB); }   // <= nB: the phase always advances a lane
     else if (nS > 0) phase = ST_SHADE;
     else if (nF > 0) phase = ST_FRONT;
-    else if (can_refill) continue;
     else if (nB > 0) phase = ST_BLAS;
-    else if (!exhausted) { if (nD > 0 && nD < P.refill_min) { /* force a refill below the threshold */
-        unsigned long long m2 = __ballot(st == ST_DEAD);
-        unsigned int base = 0;
-        if (lane == 0) base = atomicAdd(next, (unsigned int)nD);
-        base = __shfl(base, 0, 64);
-        if (base + (unsigned int)nD >= total) exhausted = true;
-        if (st == ST_DEAD) {
-          unsigned int idx = base + (unsigned int)__popcll(m2 & lt_mask);
-          if (idx < total) {
-            int tile = (int)(idx >> 6), l = (int)(idx & 63u);
-            int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
-            x = tx * 8 + (l & 7);
-            y = (P.first_group_row + ty * P.row_stride) * 8 + (l >> 3);
-            if (x < P.region_w && y < P.region_h) {
-              st = ST_FRONT;
-              seed = P.seed; ray_i = 0; k = 0;
-              avg = mk3(0, 0, 0); res = mk3(0, 0, 0); energy = mk3(1, 1, 1);
-              camera_ray<kPOffAfterScene>(P, x, y, seed, o, d);
-            }
-          }
-        }
-      }
-      continue;
-    } else break;
+    else if (exhausted) break;       // every lane dead and no work left
+    else continue;                   // every fetched slot fell outside the region: fetch again
 
     if (phase == ST_FRONT) {
       // ---------------- FRONT / RESUME: Trace() up to the next triangle-BVH visit (RS:364-383) ----------------
@@ -704,10 +694,7 @@ __global__ __launch_bounds__(256) void k_sched(DevScene S, FrameParams P, float4
     } else if (phase == ST_BLAS) {
       // ---------------- BLAS: triangle BVH of one MeshObject, resumable ----------------
       bool mine = st == ST_BLAS;
-      float pad = f_max(f_max(f_abs(o.x), f_abs(o.y)), f_abs(o.z)) * 1.52587890625e-5f;
-      v3 idir = mk3(blas_rcp(d.x), blas_rcp(d.y), blas_rcp(d.z));
-      v3 nop = mk3(-((o.x + pad) * idir.x), -((o.y + pad) * idir.y), -((o.z + pad) * idir.z));
-      v3 nom = mk3(-((o.x - pad) * idir.x), -((o.y - pad) * idir.y), -((o.z - pad) * idir.z));
+      BlasRay R = blas_ray(o, d);
       bool active = mine && cur != kBlasDone;
       unsigned int steps = 0;
       for (;;) {
@@ -720,45 +707,10 @@ __global__ __launch_bounds__(256) void k_sched(DevScene S, FrameParams P, float4
         int nI = __popcll(__ballot(interior));
         int nL = __popcll(mA) - nI;
         if (nI >= nL) {
-          if (interior) {
-            if (COUNT) lc.blas_nodes++;
-            const float4* n = S.blas_nodes + 4 * (size_t)cur;
-            float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
-            float tb = best.t;
-            float a1x = f_fma(q0.x, idir.x, nop.x), a2x = f_fma(q0.w, idir.x, nom.x);
-            float a1y = f_fma(q0.y, idir.y, nop.y), a2y = f_fma(q1.x, idir.y, nom.y);
-            float a1z = f_fma(q0.z, idir.z, nop.z), a2z = f_fma(q1.y, idir.z, nom.z);
-            float tn0 = f_max(f_max(f_min(a1x, a2x), f_min(a1y, a2y)), f_max(f_min(a1z, a2z), 0.0f));
-            float tf0 = f_min(f_min(f_max(a1x, a2x), f_max(a1y, a2y)), f_min(f_max(a1z, a2z), tb));
-            float b1x = f_fma(q1.z, idir.x, nop.x), b2x = f_fma(q2.y, idir.x, nom.x);
-            float b1y = f_fma(q1.w, idir.y, nop.y), b2y = f_fma(q2.z, idir.y, nom.y);
-            float b1z = f_fma(q2.x, idir.z, nop.z), b2z = f_fma(q2.w, idir.z, nom.z);
-            float tn1 = f_max(f_max(f_min(b1x, b2x), f_min(b1y, b2y)), f_max(f_min(b1z, b2z), 0.0f));
-            float tf1 = f_min(f_min(f_max(b1x, b2x), f_max(b1y, b2y)), f_min(f_max(b1z, b2z), tb));
-            bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
-            int32_t c0 = as_int(q3.x), c1 = as_int(q3.y);
-            if (h0 && h1) {
-              bool swap = tn1 < tn0;
-              bl[sp * 64] = swap ? c0 : c1;
-              sp++;
-              cur = swap ? c1 : c0;
-            } else if (h0) {
-              cur = c0;
-            } else if (h1) {
-              cur = c1;
-            } else if (sp == 0) {
-              cur = kBlasDone;
-            } else {
-              sp--;
-              cur = bl[sp * 64];
-            }
-          }
-        } else {
-          if (active && !interior) {
-            test_leaf<COUNT>(S, cur, o, d, best, best_i, lc);
-            if (sp == 0) cur = kBlasDone;
-            else { sp--; cur = bl[sp * 64]; }
-          }
+          if (interior) cur = blas_node_step<COUNT>(S, cur, R, best.t, bl, sp, lc);
+        } else if (active && !interior) {
+          test_leaf<COUNT>(S, cur, o, d, best, best_i, lc);
+          cur = blas_pop(bl, sp);
         }
         active = mine && cur != kBlasDone;
       }
@@ -785,7 +737,7 @@ __global__ __launch_bounds__(256) void k_sched(DevScene S, FrameParams P, float4
       }
     }
   }
-  if (watchdog && lane == 0) atomicAdd(&ctr->watchdog, 1ull);
+  if (watchdog && (threadIdx.x & 63) == 0) atomicAdd(&ctr->watchdog, 1ull);
   flush_counters<COUNT>(lc, ctr);
 }
 
