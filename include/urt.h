@@ -146,7 +146,7 @@ typedef struct urt_counters {
  *          "kernel_mode" (0 = one thread per pixel; 1 = one launch per bounce over compacted path queues;
  *                         2 = persistent waves with in-wave path regeneration;
  *                         3 = 2 + lanes scheduled by phase inside the wave, the default),
- *          "block_threads" (64 | 128 | 256), "xcd_run" (>= 1), "refill_min" (1..64), "waves_per_cu" (1..32),
+ *          "block_threads" (64 | 128 | 256), "xcd_run" (>= 1), "refill_min" (1..64), "waves_per_cu" (0 = auto, 1..32),
  *          "blas_min" / "blas_exit" (1..64, mode 3)
  *          — tuning knobs; they change speed only, never pixels. */
 URT_API int urt_set_option(urt_context* ctx, const char* name, int value);

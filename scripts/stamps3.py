@@ -1,0 +1,25 @@
+import sys, ctypes as C
+sys.path.insert(0, '.')
+import numpy as np
+from unityraytracer_amd import Context, RayTraceMaster, scenes, _lib
+ctx = Context(0)
+lib = _lib.load()
+lib.urt_debug_read_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+for (w, h, b) in ((1920, 1080, 8), (3840, 2160, 8)):
+    sc = scenes.config3(w, h); sc.num_bounces = b
+    ctx.set_option("kernel_mode", 3)
+    m = RayTraceMaster(ctx, sc)
+    for _ in range(3): m.OnRenderImage()
+    ctx.synchronize()
+    nw = 4096
+    st = np.zeros((nw, 16), np.uint64)
+    lib.urt_debug_read_stamps(ctx._h, st.ctypes.data_as(C.c_void_p), nw * 16)
+    t = st[:, 0:4].astype(np.float64) / 100.0; lanes = st[:, 4:8].astype(np.float64); trips = st[:, 8:12].astype(np.float64)
+    life = (st[:, 13] - st[:, 12]).astype(np.float64) / 100.0
+    end = (st[:, 13] - st[:, 12].min()).astype(np.float64) / 100.0
+    names = ["FRONT", "BLAS", "SHADE"]
+    print(f"{w}x{h} b={b}: wave lifetime mean {life.mean():.0f} us, end p50 {np.median(end):.0f} p90 {np.percentile(end, 90):.0f} max {end.max():.0f} us")
+    for q in range(3):
+        print(f"   {names[q]:5s}: {t[:, q].sum() / life.sum() * 100:5.1f} % of wave time, {trips[:, q].mean():7.1f} trips/wave, {lanes[:, q].sum() / max(1, trips[:, q].sum()):5.1f} lanes/trip, {t[:, q].sum() / max(1, trips[:, q].sum()):7.2f} us/trip")
+    print(f"   BLAS inner: {trips[:, 3].mean():8.1f} steps/wave, {lanes[:, 3].sum() / max(1, trips[:, 3].sum()):5.1f} active lanes/step, {t[:, 1].sum() / max(1, trips[:, 3].sum()) * 1000:7.1f} ns/step")
+    m.OnDisable()

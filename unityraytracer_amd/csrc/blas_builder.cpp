@@ -42,7 +42,7 @@ struct Box {
 };
 
 constexpr int kBins = 16;
-constexpr int kLeafMax = 4;      // SAH leaves
+int g_leaf_max = 4;              // SAH leaves (tunable: URT_BLAS_LEAF_MAX / urt_set_option "blas_leaf_max")
 constexpr int kLeafHardMax = 8;  // encoding limit (3 bits)
 
 struct Builder {
@@ -67,7 +67,7 @@ struct Builder {
     box.reset();
     Box cb; cb.reset();
     for (int q = lo; q < hi; q++) { box.grow(prims[q].lo, prims[q].hi); cb.grow(prims[q].c, prims[q].c); }
-    if (n <= kLeafMax) return make_leaf(lo, hi);
+    if (n <= g_leaf_max) return make_leaf(lo, hi);
 
     // binned SAH over the three axes
     int best_axis = -1, best_bin = -1;
@@ -131,6 +131,9 @@ struct Builder {
 };
 
 }  // namespace
+
+void set_blas_leaf_max(int n) { g_leaf_max = std::min(std::max(n, 1), kLeafHardMax); }
+int get_blas_leaf_max() { return g_leaf_max; }
 
 bool build_blas(const uint8_t* mesh_objects, int n_meshes, const float* vertices, int n_vertices, const int32_t* indices,
                 int n_indices, const float* normals, int n_normals, BlasResult& out, std::string& err) {

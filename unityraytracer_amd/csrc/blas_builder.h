@@ -22,6 +22,10 @@ struct BlasResult {
   int max_depth = 0;                   // deepest level (root = 1): bound on the traversal stack
 };
 
+// largest number of triangles the SAH builder puts in a leaf (1..8, default 4); process-wide
+void set_blas_leaf_max(int n);
+int get_blas_leaf_max();
+
 // mesh_objects: n_meshes records of 112 bytes (urt_MeshObject).  Returns false and sets err when the
 // buffers are inconsistent (an index outside _Vertices, a MeshObject range outside _Indices).
 bool build_blas(const uint8_t* mesh_objects, int n_meshes, const float* vertices, int n_vertices, const int32_t* indices,

@@ -87,7 +87,7 @@ struct urt_context {
   float trace_ms = 0;
 
   int opt_count_stats = 0, opt_time_dispatch = 0, opt_kernel_mode = 3;
-  int opt_block_threads = 64, opt_xcd_run = 1, opt_refill_min = 48, opt_waves_per_cu = 16, opt_blas_min = 16, opt_blas_exit = 8;
+  int opt_block_threads = 64, opt_xcd_run = 1, opt_refill_min = 48, opt_waves_per_cu = 0 /* auto */, opt_blas_min = 16, opt_blas_exit = 8;
 };
 
 namespace {
@@ -339,9 +339,18 @@ int do_dispatch(urt_context* ctx, int kernel, int gx, int gy, int gz, int first_
   hipError_t le;
   if (mode == 1) le = launch_wavefront(S, P, ctx->q, res->dev, ctx->d_counters, count, ctx->stream);
   else if (mode == 2 || mode == 3) {
+    if (mode == 3) P.block_threads = 64;                       // one wave per workgroup: independent scheduling, 5 waves/SIMD
     int waves_per_block = P.block_threads / 64;
     long want = ((long)P.tiles_x * P.n_strips + waves_per_block - 1) / waves_per_block;
-    long resident = (long)ctx->n_cus * ctx->opt_waves_per_cu / waves_per_block;
+    // resident waves per CU: small frames are bound by the latency chain of their last paths and want few, fat waves;
+    // large frames are throughput-bound and want every wave slot the registers allow (measured: 1080p best at 12,
+    // 2160p at 20).  auto = about 10 tiles of work per wave, clamped to [8, 20].
+    int wpc = ctx->opt_waves_per_cu;
+    if (wpc <= 0) {
+      long tiles = (long)P.tiles_x * P.n_strips;
+      wpc = (int)std::max(8L, std::min(20L, tiles / ((long)ctx->n_cus * 10)));
+    }
+    long resident = (long)ctx->n_cus * wpc / waves_per_block;
     int nb = (int)std::max(1L, std::min(want, resident));
     le = mode == 2 ? launch_persist(S, P, res->dev, ctx->d_counters, ctx->d_next, nb, count, ctx->stream)
                    : launch_sched(S, P, res->dev, ctx->d_counters, ctx->d_next, nb, count, ctx->stream);
@@ -685,6 +694,10 @@ int urt_set_option(urt_context* ctx, const char* name, int value) {
   } else if (std::strcmp(name, "block_threads") == 0) {
     if (value != 64 && value != 128 && value != 256) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "block_threads must be 64, 128 or 256");
     ctx->opt_block_threads = value;
+  } else if (std::strcmp(name, "blas_leaf_max") == 0) {
+    if (value < 1 || value > 8) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "blas_leaf_max must be in [1, 8]");
+    set_blas_leaf_max(value);
+    ctx->scene_dirty = true;
   } else if (std::strcmp(name, "blas_min") == 0) {
     if (value < 1 || value > 64) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "blas_min must be in [1, 64]");
     ctx->opt_blas_min = value;
@@ -695,7 +708,7 @@ int urt_set_option(urt_context* ctx, const char* name, int value) {
     if (value < 1 || value > 64) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "refill_min must be in [1, 64]");
     ctx->opt_refill_min = value;
   } else if (std::strcmp(name, "waves_per_cu") == 0) {
-    if (value < 1 || value > 32) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "waves_per_cu must be in [1, 32]");
+    if (value < 0 || value > 32) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "waves_per_cu must be in [0, 32] (0 = auto)");
     ctx->opt_waves_per_cu = value;
   } else if (std::strcmp(name, "xcd_run") == 0) {
     if (value < 1 || value > 4096) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "xcd_run must be in [1, 4096]");
@@ -741,7 +754,7 @@ int urt_reset_counters(urt_context* ctx) {
 /* diagnostic builds only: per-wave (start, pool-exhausted, end, iters<<32|fetches) of the last persistent launch */
 __attribute__((visibility("default"))) int urt_debug_read_stamps(urt_context* ctx, unsigned long long* out, int n_waves) {
   (void)hipStreamSynchronize(ctx->stream);
-  return (int)hipMemcpy(out, (char*)ctx->d_next + 64, (size_t)n_waves * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+  return (int)hipMemcpy(out, (char*)ctx->d_next + 64, (size_t)n_waves * sizeof(unsigned long long), hipMemcpyDeviceToHost);   // n_waves = number of u64 words
 }
 #endif
 

@@ -581,7 +581,7 @@ static constexpr unsigned int kWatchdogIters = 1u << 24;    // scheduler trips p
 static constexpr unsigned int kWatchdogSteps = 1u << 24;    // traversal steps per scheduled BLAS phase
 
 template <bool COUNT>
-__global__ __launch_bounds__(256) void k_sched(DevScene S, FrameParams P, float4* __restrict__ result, DevCounters* ctr,
+__global__ __launch_bounds__(64, 5) void k_sched(DevScene S, FrameParams P, float4* __restrict__ result, DevCounters* ctr,
                                                unsigned int* __restrict__ next) {
   int *tl, *bl;
   lane_stacks(P, tl, bl);
@@ -599,6 +599,10 @@ __global__ __launch_bounds__(256) void k_sched(DevScene S, FrameParams P, float4
   int32_t cur = kBlasDone; int sp = 0, best_i = -1;   // triangle-BVH cursor of the current MeshObject
   unsigned int wave_iters = 0;
   bool watchdog = false;
+#ifdef URT_STAMPS
+  unsigned long long ph_t[4] = {0, 0, 0, 0}, ph_lanes[4] = {0, 0, 0, 0}, ph_trips[4] = {0, 0, 0, 0};   // FRONT, BLAS, SHADE, blas inner trips
+  unsigned long long t_begin = wall_clock64();
+#endif
 
   for (;;) {
     if (watchdog) break;
@@ -631,6 +635,12 @@ __global__ __launch_bounds__(256) void k_sched(DevScene S, FrameParams P, float4
     else if (exhausted) break;       // every lane dead and no work left
     else continue;                   // every fetched slot fell outside the region: fetch again
 
+#ifdef URT_STAMPS
+    unsigned long long t_ph = wall_clock64();
+    int ph_id = phase == ST_FRONT ? 0 : phase == ST_BLAS ? 1 : 2;
+    ph_lanes[ph_id] += (unsigned long long)(phase == ST_FRONT ? nF : phase == ST_BLAS ? nB : nS);
+    ph_trips[ph_id]++;
+#endif
     if (phase == ST_FRONT) {
       // ---------------- FRONT / RESUME: Trace() up to the next triangle-BVH visit (RS:364-383) ----------------
       if (st == ST_FRONT || st == ST_RESUME) {
@@ -701,6 +711,9 @@ __global__ __launch_bounds__(256) void k_sched(DevScene S, FrameParams P, float4
         unsigned long long mA = __ballot(active);
         if (__popcll(mA) < exit_below) break;
         if (++steps > kWatchdogSteps) { watchdog = true; break; }
+#ifdef URT_STAMPS
+        ph_trips[3]++; ph_lanes[3] += (unsigned long long)__popcll(mA);
+#endif
         // majority vote: this trip runs EITHER the interior-node step OR the leaf step, for the lanes that hold that kind
         // of cursor (the others wait one trip) — so a trip costs one of the two bodies, not their sum.
         bool interior = active && cur >= 0;
@@ -736,7 +749,18 @@ __global__ __launch_bounds__(256) void k_sched(DevScene S, FrameParams P, float4
         }
       }
     }
+#ifdef URT_STAMPS
+    ph_t[ph_id] += wall_clock64() - t_ph;
+#endif
   }
+#ifdef URT_STAMPS
+  if ((threadIdx.x & 63) == 0) {
+    unsigned long long* sp_ = (unsigned long long*)(next + 16);
+    size_t w = ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16;
+    for (int q = 0; q < 4; q++) { sp_[w + q] = ph_t[q]; sp_[w + 4 + q] = ph_lanes[q]; sp_[w + 8 + q] = ph_trips[q]; }
+    sp_[w + 12] = t_begin; sp_[w + 13] = wall_clock64();
+  }
+#endif
   if (watchdog && (threadIdx.x & 63) == 0) atomicAdd(&ctr->watchdog, 1ull);
   flush_counters<COUNT>(lc, ctr);
 }
@@ -922,6 +946,7 @@ hipError_t launch_persist(const DevScene& S, const FrameParams& P, float4* resul
 hipError_t launch_sched(const DevScene& S, const FrameParams& P, float4* result, DevCounters* ctr, unsigned int* next,
                         int n_blocks, bool count, hipStream_t st) {
   if (n_blocks <= 0) return hipSuccess;
+  if (P.block_threads != 64) return hipErrorInvalidValue;     // k_sched is built for one wave per workgroup (launch bounds 64, 5 waves/SIMD)
   hipError_t e = hipMemsetAsync(next, 0, sizeof(unsigned int), st);
   if (e != hipSuccess) return e;
   size_t lds = stack_lds_bytes(P);
