@@ -78,28 +78,40 @@ __device__ __forceinline__ void intersect_sphere(const DevScene& S, int idx, v3 
 // upload), and the closer-hit rule RS:251 extended by "equal t inside one IntersectMeshObject call goes to the lower
 // index slot" (A.4) — `best_i` is the index slot of a hit made in THIS call, or -1.
 template <bool COUNT>
+__device__ __forceinline__ void test_triangle(float4 r0, float4 r1, float4 r2, int slot_in_leaf_order, v3 o, v3 d, HitRec& best, int& best_i,
+                                              LocalCounters& lc) {
+  if (COUNT) lc.tri_tests++;
+  v3 edge1 = xyz(r1), edge2 = xyz(r2);
+  v3 pvec = cross(d, edge2);
+  float det = dot(edge1, pvec);
+  if (det < kEPSILON) return;
+  float inv_det = 1.0f / det;
+  v3 tvec = o - xyz(r0);
+  float u = dot(tvec, pvec) * inv_det;
+  if (u < 0.0f || u > 1.0f) return;
+  v3 qvec = cross(tvec, edge1);
+  float v = dot(d, qvec) * inv_det;
+  if (v < 0.0f || u + v > 1.0f) return;
+  float t = dot(edge2, qvec) * inv_det;
+  int islot = as_int(r0.w);
+  bool closer = (t > 0 && t < best.t) || (t > 0 && t == best.t && best_i >= 0 && islot < best_i);
+  if (closer) { best.t = t; best.kind = 3; best.id = slot_in_leaf_order; best.u = u; best.v = v; best_i = islot; }
+}
+
+template <bool COUNT>
 __device__ __forceinline__ void test_leaf(const DevScene& S, int32_t leaf, v3 o, v3 d, HitRec& best, int& best_i, LocalCounters& lc) {
   uint32_t code = ~(uint32_t)leaf;
   uint32_t first = code >> 3, cnt = (code & 7u) + 1u;
-  for (uint32_t k = 0; k < cnt; k++) {
-    if (COUNT) lc.tri_tests++;
-    const float4* tv = S.tri_verts + 3 * (size_t)(first + k);
-    float4 r0 = tv[0], r1 = tv[1], r2 = tv[2];
-    v3 edge1 = xyz(r1), edge2 = xyz(r2);
-    v3 pvec = cross(d, edge2);
-    float det = dot(edge1, pvec);
-    if (det < kEPSILON) continue;
-    float inv_det = 1.0f / det;
-    v3 tvec = o - xyz(r0);
-    float u = dot(tvec, pvec) * inv_det;
-    if (u < 0.0f || u > 1.0f) continue;
-    v3 qvec = cross(tvec, edge1);
-    float v = dot(d, qvec) * inv_det;
-    if (v < 0.0f || u + v > 1.0f) continue;
-    float t = dot(edge2, qvec) * inv_det;
-    int islot = as_int(r0.w);
-    bool closer = (t > 0 && t < best.t) || (t > 0 && t == best.t && best_i >= 0 && islot < best_i);
-    if (closer) { best.t = t; best.kind = 3; best.id = (int)(first + k); best.u = u; best.v = v; best_i = islot; }
+  // two triangles per round: both records are requested before either is tested, so a leaf of 4 costs two memory
+  // round trips on the dependent chain instead of four
+  for (uint32_t k = 0; k < cnt; k += 2) {
+    const float4* ta = S.tri_verts + 3 * (size_t)(first + k);
+    bool two = k + 1 < cnt;
+    const float4* tb = two ? ta + 3 : ta;
+    float4 a0 = ta[0], a1 = ta[1], a2 = ta[2];
+    float4 b0 = tb[0], b1 = tb[1], b2 = tb[2];
+    test_triangle<COUNT>(a0, a1, a2, (int)(first + k), o, d, best, best_i, lc);
+    if (two) test_triangle<COUNT>(b0, b1, b2, (int)(first + k + 1), o, d, best, best_i, lc);
   }
 }
 
