@@ -71,6 +71,7 @@ struct urt_context {
   DevScene ds{};
   std::vector<void*> scene_allocs;
   int tlas_stack = 2, blas_stack = 2;
+  unsigned int watchdog_steps = 1u << 16;
   float4* zero_sky = nullptr;
 
   // wavefront queues
@@ -230,6 +231,9 @@ int prepare_scene(urt_context* ctx) {
     return fail(ctx, URT_ERR_SCENE, "object-level BVH deeper than the reference's 32-entry traversal stack (RS:73-74)");
   ctx->tlas_stack = std::max(2, lv + 1);
   ctx->blas_stack = std::max(2, blas.max_depth + 1);
+  // a ray with NaN components passes every slab test and walks the whole tree once: (nodes + leaves) trips per lane, and the
+  // majority vote can make a lane wait a trip for every trip it runs; 8x that is a bound no correct traversal reaches
+  ctx->watchdog_steps = (unsigned int)std::min<size_t>(0x7fffffffu, 8 * (blas.nodes.size() / kBlasNodeFloats + blas.tri_slot.size()) + 4096);
   if ((size_t)(ctx->tlas_stack + ctx->blas_stack) * 64 * 4 * sizeof(int) > 64 * 1024)   // at the largest workgroup (4 waves)
     return fail(ctx, URT_ERR_SCENE, "traversal stacks exceed the 64 KiB LDS budget per workgroup");
   ctx->scene_dirty = false;
@@ -309,7 +313,7 @@ int do_dispatch(urt_context* ctx, int kernel, int gx, int gy, int gz, int first_
   int group_rows = (P.region_h + 7) / 8;
   P.first_group_row = first_row; P.row_stride = row_stride;
   P.n_strips = first_row < group_rows ? (group_rows - first_row + row_stride - 1) / row_stride : 0;
-  P.tlas_stack = ctx->tlas_stack; P.blas_stack = ctx->blas_stack;
+  P.tlas_stack = ctx->tlas_stack; P.blas_stack = ctx->blas_stack; P.watchdog_steps = ctx->watchdog_steps;
   P.block_threads = ctx->opt_block_threads; P.xcd_run = ctx->opt_xcd_run; P.refill_min = ctx->opt_refill_min; P.blas_min = ctx->opt_blas_min; P.blas_exit = ctx->opt_blas_exit;
   if (P.n_strips == 0 || P.tiles_x == 0) return URT_OK;
 

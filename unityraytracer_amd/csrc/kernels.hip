@@ -590,7 +590,6 @@ __global__ __launch_bounds__(256) void k_persist(DevScene S, FrameParams P, floa
 // ---------------------------------------------------------------------------------------------------
 enum : int { ST_DEAD = 0, ST_FRONT = 1, ST_RESUME = 2, ST_BLAS = 3, ST_SHADE = 4 };
 static constexpr unsigned int kWatchdogIters = 1u << 24;    // scheduler trips per wave (a frame needs ~1e3-1e5)
-static constexpr unsigned int kWatchdogSteps = 1u << 24;    // traversal steps per scheduled BLAS phase
 
 template <bool COUNT>
 __global__ __launch_bounds__(64, 5) void k_sched(DevScene S, FrameParams P, float4* __restrict__ result, DevCounters* ctr,
@@ -722,7 +721,7 @@ __global__ __launch_bounds__(64, 5) void k_sched(DevScene S, FrameParams P, floa
       for (;;) {
         unsigned long long mA = __ballot(active);
         if (__popcll(mA) < exit_below) break;
-        if (++steps > kWatchdogSteps) { watchdog = true; break; }
+        if (++steps > P.watchdog_steps) { watchdog = true; break; }
 #ifdef URT_STAMPS
         ph_trips[3]++; ph_lanes[3] += (unsigned long long)__popcll(mA);
 #endif

@@ -55,6 +55,7 @@ struct FrameParams {
   int refill_min;           // persistent modes: dead lanes per wave that trigger a refill (1..64)
   int blas_min;             // mode 3: lanes parked in BLAS before the traversal phase is scheduled (1..64)
   int blas_exit;            // mode 3: the traversal phase yields when fewer lanes than this are still traversing (1..64)
+  unsigned int watchdog_steps;  // cap on traversal trips per scheduled BLAS phase: a few times (nodes + leaves) of the scene
 };
 
 static constexpr int kCounterShards = 256;   // power of two; a block adds to shard blockIdx & (N-1)
