@@ -102,39 +102,81 @@ def main():
     scene = scenes.CONFIGS[args.config](width, height)
 
     ctx = Context(dev_index)
-    ctx.set_stream(torch.cuda.current_stream(device).cuda_stream)      # one in-order stream for kernels + collective
+    # ONE explicit (non-default) stream shared by torch and the library: the HIP kernels, the pack/unpack kernels and the
+    # events that order the collective all live on it.  (torch's default stream has handle 0, which the C ABI reads as "use
+    # the library's own stream" — the two would then be unordered.)
+    main_stream = torch.cuda.Stream(device=device)
+    torch.cuda.set_stream(main_stream)
+    assert main_stream.cuda_stream != 0
+    ctx.set_stream(main_stream.cuda_stream)
     if args.kernel_mode is not None:
         ctx.set_option("kernel_mode", args.kernel_mode)
     ctx.set_option("time_dispatch", 1)
     master = RayTraceMaster(ctx, scene, rank=rank, world_size=world)
 
-    packed = None
+    # ---- multi-GPU frame-end gather, software-pipelined ---------------------------------------------------------------
+    # Frame i's strips are packed on the render stream; the ONE collective of the frame (gather to rank 0) runs on a second
+    # stream and overlaps with the rendering of frame i+1; rank 0 de-interleaves frame i while it renders frame i+1.
+    # Buffers are double-buffered and every reuse is ordered by events.  URT_BENCH_NO_OVERLAP=1 serialises everything.
+    overlap = world > 1 and os.environ.get("URT_BENCH_NO_OVERLAP") != "1"
     if world > 1:
         n_floats = strips.packed_rows(height, world) * width * 4
-        packed = torch.zeros(n_floats, dtype=torch.float32, device=device)
-        gathered = [torch.empty_like(packed) for _ in range(world)] if rank == 0 else None
+        packed = [torch.zeros(n_floats, dtype=torch.float32, device=device) for _ in range(2)]
+        gathered = [[torch.empty(n_floats, dtype=torch.float32, device=device) for _ in range(world)] for _ in range(2)] if rank == 0 else [None, None]
+        comm_stream = torch.cuda.Stream(device=device) if overlap else main_stream
+        ev_pack = [torch.cuda.Event() for _ in range(2)]
+        ev_gather = [torch.cuda.Event() for _ in range(2)]
         full = None
         if rank == 0:
             from unityraytracer_amd import RenderTexture
             full = RenderTexture(ctx, width, height)
+    state = {"i": 0, "pending": None}
+
+    def do_gather(slot):
+        if backend == "nccl":
+            dist.gather(packed[slot], gathered[slot], dst=0)              # the ONE collective of the frame
+        else:                                                             # rehearsal: same data path through host memory
+            host = packed[slot].cpu()
+            parts = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
+            dist.gather(host, parts, dst=0)
+            if rank == 0:
+                for r in range(world):
+                    gathered[slot][r].copy_(parts[r])
+
+    def unpack(slot):
+        if rank == 0:
+            for r in range(world):
+                full.unpack_rows(r, world, gathered[slot][r].data_ptr())
 
     def step():
         master.OnRenderImage()
-        if world > 1:
-            master._converged.pack_rows(rank, world, packed.data_ptr())
-            if backend == "nccl":
-                dist.gather(packed, gathered, dst=0)                    # the ONE collective of the frame
-            else:                                                       # rehearsal: same data path through host memory
-                torch.cuda.synchronize(device)
-                host = packed.cpu()
-                parts = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
-                dist.gather(host, parts, dst=0)
-                if rank == 0:
-                    for r in range(world):
-                        gathered[r].copy_(parts[r])
-            if rank == 0:
-                for r in range(world):
-                    full.unpack_rows(r, world, gathered[r].data_ptr())
+        if world == 1:
+            return
+        i = state["i"]
+        slot = i % 2
+        if i >= 2:
+            main_stream.wait_event(ev_gather[slot])                       # the gather of frame i-2 has finished reading packed[slot]
+        master._converged.pack_rows(rank, world, packed[slot].data_ptr())
+        ev_pack[slot].record(main_stream)
+        with torch.cuda.stream(comm_stream):
+            comm_stream.wait_event(ev_pack[slot])
+            do_gather(slot)
+            ev_gather[slot].record(comm_stream)
+        if overlap:
+            if state["pending"] is not None:                              # de-interleave frame i-1 while frame i's gather is in flight
+                main_stream.wait_event(ev_gather[state["pending"]])
+                unpack(state["pending"])
+            state["pending"] = slot
+        else:
+            main_stream.wait_event(ev_gather[slot])
+            unpack(slot)
+        state["i"] = i + 1
+
+    def drain():
+        if world > 1 and overlap and state["pending"] is not None:
+            main_stream.wait_event(ev_gather[state["pending"]])
+            unpack(state["pending"])
+            state["pending"] = None
 
     def fence():
         if world > 1:
@@ -143,11 +185,13 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    drain()
     fence()
     ctx.reset_counters()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()                                   # the last frame's strips are on rank 0 and de-interleaved inside the timed region
     fence()
     elapsed = time.perf_counter() - t0
     c = ctx.counters()
@@ -230,7 +274,7 @@ def main():
             "config": {"workload": f"{args.config}: {scene.name}, {scene.n_triangles} triangles + triangle BVH, {len(scene.spheres)} spheres, "
                                    f"ground plane, equirect sky; numBounces {scene.num_bounces}, numRays {scene.num_rays}",
                        "frame": [width, height], "pixels_per_gpu": width * height // world,
-                       "partition": "8-row strips round-robin over ranks, one gather per frame" if world > 1 else "single GPU",
+                       "partition": ("8-row strips round-robin over ranks, one gather per frame" + (", gather overlapped with the next frame" if overlap else "")) if world > 1 else "single GPU",
                        "rays_per_step": int(total_rays / args.steps), "kernel_mode": args.kernel_mode if args.kernel_mode is not None else 3},
             "roofline": roofline, "cpu_baseline": cpu,
         }
