@@ -22,6 +22,7 @@
  *    URT_ERR_NO_DEVICE if no HIP device is usable.
  */
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 #include "urt_types.h"
 
@@ -172,6 +173,16 @@ URT_API int urt_host_sphere_leaf_bounds(const void* spheres, int n_spheres, int 
 URT_API int urt_host_object_bvh_length(int n_objects);
 URT_API int urt_host_build_object_bvh(const urt_BVHNode* leaves, int n_objects, urt_BVHNode* out_nodes, int capacity);
 URT_API const char* urt_host_last_error(void);
+
+/* ---- host-side image I/O (no GPU needed) ---------------------------------- */
+/* Radiance RGBE (.hdr, FORMAT=32-bit_rle_rgbe, flat or new-style RLE scanlines) -> RGBA32F, row 0 = bottom: the pixels a
+ * caller hands to urt_texture_set_pixels for "_SkyboxTexture" (RM:776).  out_rgba == NULL queries the size. */
+URT_API int urt_host_load_hdr(const char* path, int* out_width, int* out_height, float* out_rgba, size_t capacity_floats);
+/* RGBA32F image (row 0 = bottom) -> .pfm (float RGB, bottom row first). */
+URT_API int urt_host_write_pfm(const char* path, const float* rgba, int width, int height);
+/* RGBA32F linear image -> 8-bit sRGB .png (what ScreenCapture.CaptureScreenshot produces for RM:762). */
+URT_API int urt_host_write_png(const char* path, const float* rgba, int width, int height);
+URT_API const char* urt_host_io_last_error(void);
 
 /* ---- introspection for tests (host only, no GPU needed) ------------------------------------ */
 /* Run the library's triangle-BVH builder — the one urt_shader_dispatch uses — over host copies of

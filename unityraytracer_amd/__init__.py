@@ -6,7 +6,7 @@ include/urt.h).  The Python modules are the host-side mirror of the reference's 
 Importing this package does not load the library; creating a `Context` does, and fails loudly when
 the library has not been built or no GPU is usable (there is no CPU fallback).
 """
-from . import host_scene, scenes, strips  # noqa: F401
+from . import host_io, host_scene, scenes, strips  # noqa: F401
 from ._lib import ABI_SYMBOLS, LIB_PATH, UrtError  # noqa: F401
 from .ray_trace_master import RayTraceMaster, RayTraceObject  # noqa: F401
 from .unity_api import (ComputeBuffer, ComputeShader, Context, Graphics, Material, RenderTexture, Texture2D,  # noqa: F401

@@ -1,0 +1,38 @@
+"""Host-side image I/O through the C ABI (csrc/host_io.cpp): Radiance .hdr sky loader and frame writers
+(.pfm / .png, f4).  No GPU needed."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import UrtError
+
+
+def _check(lib, rc):
+    if rc != 0:
+        raise UrtError(rc, lib.urt_host_io_last_error().decode())
+
+
+def load_hdr(path: str) -> np.ndarray:
+    """Radiance RGBE file -> (H, W, 4) float32, row 0 = bottom (ready for RenderTexture.SetPixels as the sky)."""
+    lib = _lib.load()
+    w, h = C.c_int(), C.c_int()
+    _check(lib, lib.urt_host_load_hdr(path.encode(), C.byref(w), C.byref(h), None, 0))
+    out = np.zeros((h.value, w.value, 4), dtype=np.float32)
+    _check(lib, lib.urt_host_load_hdr(path.encode(), C.byref(w), C.byref(h), out.ctypes.data_as(C.c_void_p), out.size))
+    return out
+
+
+def write_pfm(path: str, rgba: np.ndarray):
+    lib = _lib.load()
+    a = np.ascontiguousarray(rgba, dtype=np.float32)
+    _check(lib, lib.urt_host_write_pfm(path.encode(), a.ctypes.data_as(C.c_void_p), a.shape[1], a.shape[0]))
+
+
+def write_png(path: str, rgba: np.ndarray):
+    """Linear RGBA32F -> 8-bit sRGB PNG (the display transfer of the reference's linear-colour-space project)."""
+    lib = _lib.load()
+    a = np.ascontiguousarray(rgba, dtype=np.float32)
+    _check(lib, lib.urt_host_write_png(path.encode(), a.ctypes.data_as(C.c_void_p), a.shape[1], a.shape[0]))

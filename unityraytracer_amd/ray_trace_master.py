@@ -206,6 +206,15 @@ class RayTraceMaster:
     def ResetAccumulation(self):
         self._currentSample = 0
 
+    # RM:761-763: F12 -> ScreenCapture.CaptureScreenshot("Screenshots/" + Time.time + "-" + _currentSample + ".png")
+    def CaptureScreenshot(self, directory: str, time_seconds: float) -> str:
+        import os
+        from . import host_io
+        os.makedirs(directory, exist_ok=True)
+        path = os.path.join(directory, f"{time_seconds:g}-{self._currentSample}.png")
+        host_io.write_png(path, self._converged.GetPixels())
+        return path
+
     # RM:188-212
     def OnDisable(self):
         for b in (self._sphereBuffer, self._meshObjectBuffer, self._vertexBuffer, self._indexBuffer, self._normalBuffer,
