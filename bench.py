@@ -247,7 +247,13 @@ def main():
             tc = time.perf_counter()
             _, oc = o.render(mode=1, threads=cores, counters=True)
             dt = time.perf_counter() - tc
+            # single-thread figure on a bounded crop of the same frame (centre band through the mesh)
+            y0 = height // 2 - height // 32
+            t1 = time.perf_counter()
+            _, oc1 = o.render(rect=(0, y0, width, y0 + height // 16), mode=1, threads=1, counters=True)
+            dt1 = time.perf_counter() - t1
             cpu = {"value": round(oc["rays"] / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+                   "value_1_thread": round(oc1["rays"] / dt1 / 1e6, 3),
                    "sample": f"1 frame of {scene.name} {width}x{height} (frame 0 uniforms), BVH-culled scalar oracle, {cores} std::threads"}
 
     if world > 1 and os.environ.get("URT_BENCH_VERIFY") == "1":

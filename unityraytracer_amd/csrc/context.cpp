@@ -316,6 +316,8 @@ int do_dispatch(urt_context* ctx, int kernel, int gx, int gy, int gz, int first_
   P.tlas_stack = ctx->tlas_stack; P.blas_stack = ctx->blas_stack; P.watchdog_steps = ctx->watchdog_steps;
   P.block_threads = ctx->opt_block_threads; P.xcd_run = ctx->opt_xcd_run; P.refill_min = ctx->opt_refill_min; P.blas_min = ctx->opt_blas_min; P.blas_exit = ctx->opt_blas_exit;
   if (P.n_strips == 0 || P.tiles_x == 0) return URT_OK;
+  if ((uint64_t)P.tiles_x * (uint64_t)P.n_strips * 64u >= 0xffffffffull)
+    return fail(ctx, URT_ERR_INVALID_ARGUMENT, "Dispatch: more than 2^32 pixel slots in one dispatch");
 
   // region pixels this dispatch writes (threads outside Result write nothing, RS:468)
   {
