@@ -401,7 +401,7 @@ int urt_context_create(int device, urt_context** out_ctx) {
   ctx->stream = ctx->own_stream;
   e = hipMalloc((void**)&ctx->d_counters, sizeof(DevCounters) * kCounterShards);
   if (e == hipSuccess) e = hipMemset(ctx->d_counters, 0, sizeof(DevCounters) * kCounterShards);
-  if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_next, 64 + 65536 * 4 * sizeof(unsigned long long));   // [0] work counter; the rest: diagnostic stamps (URT_STAMPS builds)
+  if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_next, kWorkShards * 128 + 65536 * 16 * sizeof(unsigned long long));   // work-counter shards; the rest: diagnostic stamps (URT_STAMPS builds)
   if (e == hipSuccess) { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n > 0) ctx->n_cus = n; }
   if (e != hipSuccess) { (void)hipStreamDestroy(ctx->own_stream); delete ctx; return fail(nullptr, URT_ERR_HIP, std::string("counter allocation: ") + hipGetErrorString(e)); }
   *out_ctx = ctx;
@@ -760,7 +760,7 @@ int urt_reset_counters(urt_context* ctx) {
 /* diagnostic builds only: per-wave (start, pool-exhausted, end, iters<<32|fetches) of the last persistent launch */
 __attribute__((visibility("default"))) int urt_debug_read_stamps(urt_context* ctx, unsigned long long* out, int n_waves) {
   (void)hipStreamSynchronize(ctx->stream);
-  return (int)hipMemcpy(out, (char*)ctx->d_next + 64, (size_t)n_waves * sizeof(unsigned long long), hipMemcpyDeviceToHost);   // n_waves = number of u64 words
+  return (int)hipMemcpy(out, (char*)ctx->d_next + kWorkShards * 128, (size_t)n_waves * sizeof(unsigned long long), hipMemcpyDeviceToHost);   // n_waves = number of u64 words
 }
 #endif
 

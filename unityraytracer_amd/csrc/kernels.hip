@@ -476,27 +476,53 @@ __global__ __launch_bounds__(256) void k_mega(DevScene S, FrameParams P, float4*
   flush_counters<COUNT>(lc, ctr);
 }
 
-// Work distribution of the persistent kernels: slot idx of the frame (tile order: 64 consecutive slots = one 8x8 tile)
-// -> pixel; false for slots that fall outside the dispatched region (ragged right/top edge).
-__device__ __forceinline__ bool slot_pixel(const FrameParams& P, unsigned int idx, int& x, int& y) {
-  int tile = (int)(idx >> 6), l = (int)(idx & 63u);
-  int ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
-  x = tx * 8 + (l & 7);
-  y = (P.first_group_row + ty * P.row_stride) * 8 + (l >> 3);
+// Work distribution of the persistent kernels.  The frame is a sequence of pixel slots in tile order (64 consecutive slots
+// = one 8x8 tile).  One shared counter would be hit ~40,000 times per 1080p frame, and same-address atomics serialise at
+// ~88/us on this chip — that alone cost 0.4 ms.  So the tiles are dealt round-robin to kWorkShards counters (tile t belongs
+// to shard t % kWorkShards, each counter on its own 128-byte line); a wave draws from its home shard (its workgroup index)
+// and moves on to the next shard when that one is dry.  All shards advance at a similar pace, so the frame is still swept
+// roughly in natural order.
+struct WorkCursor {
+  unsigned int shard;       // shard this wave currently draws from
+};
+static_assert(kWorkShards == 64, "the dry-shard probe reads one counter per lane");
+
+__device__ __forceinline__ unsigned int shard_slots(unsigned int ntiles, unsigned int shard) {   // slots owned by a shard
+  return ((ntiles + kWorkShards - 1u - shard) / kWorkShards) * 64u;
+}
+
+// slot -> pixel; false for slots that fall outside the dispatched region (ragged right/top edge)
+__device__ __forceinline__ bool slot_pixel(const FrameParams& P, unsigned int tile, unsigned int l, int& x, int& y) {
+  int ty = (int)tile / P.tiles_x, tx = (int)tile - ty * P.tiles_x;
+  x = tx * 8 + (int)(l & 7u);
+  y = (P.first_group_row + ty * P.row_stride) * 8 + (int)(l >> 3);
   return x < P.region_w && y < P.region_h;
 }
 
-// The wave takes popcount(want) slots from the frame's work counter with ONE atomic; each lane of `want` gets its own slot
-// (prefix popcount).  Returns the slot or 0xffffffff; sets `exhausted` once the counter has passed `total`.
-__device__ __forceinline__ unsigned int wave_fetch_slots(unsigned long long want, bool mine, unsigned int* next, unsigned int total, bool& exhausted) {
+// The wave takes popcount(want) slots with ONE atomic; each lane of `want` gets its own slot (prefix popcount).  Returns true
+// and the pixel for lanes that received a valid one.  Sets `exhausted` when every shard is dry.
+__device__ __forceinline__ bool wave_fetch_pixels(const FrameParams& P, unsigned long long want, bool mine, unsigned int* next,
+                                                  unsigned int ntiles, WorkCursor& wc, bool& exhausted, int& x, int& y) {
   const int lane = threadIdx.x & 63;
   unsigned int n = (unsigned int)__popcll(want);
+  unsigned int own = shard_slots(ntiles, wc.shard);
   unsigned int base = 0;
-  if (lane == 0) base = atomicAdd(next, n);
+  if (lane == 0) base = atomicAdd(next + wc.shard * 32u, n);
   base = __shfl(base, 0, 64);
-  if (base + n >= total) exhausted = true;
-  unsigned int idx = base + (unsigned int)__popcll(want & ((1ull << lane) - 1ull));
-  return (mine && idx < total) ? idx : 0xffffffffu;
+  unsigned int shard = wc.shard;
+  if (base + n >= own) {   // this shard is (now) dry: every lane looks at one counter, the wave moves to the next shard with work
+    unsigned int seen = __hip_atomic_load(next + lane * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long avail = __ballot(seen < shard_slots(ntiles, (unsigned int)lane)) & ~(1ull << shard);
+    if (!avail) {
+      exhausted = true;    // counters only grow, so this is final
+    } else {
+      unsigned long long after = shard == 63u ? 0ull : avail & ~((2ull << shard) - 1ull);
+      wc.shard = (unsigned int)__builtin_ctzll(after ? after : avail);
+    }
+  }
+  unsigned int local = base + (unsigned int)__popcll(want & ((1ull << lane) - 1ull));
+  if (!mine || local >= own) return false;
+  return slot_pixel(P, (local >> 6) * kWorkShards + shard, local & 63u, x, y);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -515,7 +541,8 @@ __global__ __launch_bounds__(256) void k_persist(DevScene S, FrameParams P, floa
   int *tl, *bl;
   lane_stacks(P, tl, bl);
   LocalCounters lc;
-  const unsigned int total = (unsigned int)(P.tiles_x * P.n_strips) * 64u;
+  const unsigned int ntiles = (unsigned int)(P.tiles_x * P.n_strips);
+  WorkCursor wc; wc.shard = blockIdx.x & (kWorkShards - 1u);
   bool alive = false, exhausted = false;
 #ifdef URT_STAMPS
   unsigned long long t_start = wall_clock64(), t_exh = 0; unsigned int n_iter = 0, n_fetch = 0;
@@ -527,11 +554,11 @@ __global__ __launch_bounds__(256) void k_persist(DevScene S, FrameParams P, floa
     unsigned long long dead = __ballot(!alive);
     int ndead = __popcll(dead);
     if (!exhausted && ndead >= P.refill_min) {
-      unsigned int idx = wave_fetch_slots(dead, !alive, next, total, exhausted);
+      bool got = wave_fetch_pixels(P, dead, !alive, next, ntiles, wc, exhausted, x, y);
 #ifdef URT_STAMPS
       n_fetch++; if (exhausted && !t_exh) t_exh = wall_clock64();
 #endif
-      if (idx != 0xffffffffu && slot_pixel(P, idx, x, y)) {
+      if (got) {
         alive = true;
         px = (float)x; py = (float)y;
         seed = P.seed; ray_i = 0; k = 0;
@@ -566,7 +593,7 @@ __global__ __launch_bounds__(256) void k_persist(DevScene S, FrameParams P, floa
   }
 #ifdef URT_STAMPS
   if ((threadIdx.x & 63) == 0) {
-    unsigned long long* st = (unsigned long long*)(next + 16);
+    unsigned long long* st = (unsigned long long*)(next + kWorkShards * 32);
     size_t w = ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 4;
     st[w] = t_start; st[w + 1] = t_exh; st[w + 2] = wall_clock64(); st[w + 3] = ((unsigned long long)n_iter << 32) | n_fetch;
   }
@@ -597,7 +624,8 @@ __global__ __launch_bounds__(64, 5) void k_sched(DevScene S, FrameParams P, floa
   int *tl, *bl;
   lane_stacks(P, tl, bl);
   LocalCounters lc;
-  const unsigned int total = (unsigned int)(P.tiles_x * P.n_strips) * 64u;
+  const unsigned int ntiles = (unsigned int)(P.tiles_x * P.n_strips);
+  WorkCursor wc; wc.shard = blockIdx.x & (kWorkShards - 1u);
   bool exhausted = false;
   int st = ST_DEAD;
   // path state
@@ -625,8 +653,7 @@ __global__ __launch_bounds__(64, 5) void k_sched(DevScene S, FrameParams P, floa
     // ---- refill dead lanes from the frame's work counter (one atomic per refill): when enough lanes are dead, or when
     // nothing else is left to run ----
     if (!exhausted && nD > 0 && (nD >= P.refill_min || nB + nS + nF == 0)) {
-      unsigned int idx = wave_fetch_slots(mD, st == ST_DEAD, next, total, exhausted);
-      if (idx != 0xffffffffu && slot_pixel(P, idx, x, y)) {
+      if (wave_fetch_pixels(P, mD, st == ST_DEAD, next, ntiles, wc, exhausted, x, y)) {
         st = ST_FRONT;
         seed = P.seed; ray_i = 0; k = 0;
         avg = mk3(0, 0, 0); res = mk3(0, 0, 0); energy = mk3(1, 1, 1);
@@ -766,7 +793,7 @@ __global__ __launch_bounds__(64, 5) void k_sched(DevScene S, FrameParams P, floa
   }
 #ifdef URT_STAMPS
   if ((threadIdx.x & 63) == 0) {
-    unsigned long long* sp_ = (unsigned long long*)(next + 16);
+    unsigned long long* sp_ = (unsigned long long*)(next + kWorkShards * 32);
     size_t w = ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16;
     for (int q = 0; q < 4; q++) { sp_[w + q] = ph_t[q]; sp_[w + 4 + q] = ph_lanes[q]; sp_[w + 8 + q] = ph_trips[q]; }
     sp_[w + 12] = t_begin; sp_[w + 13] = wall_clock64();
@@ -946,7 +973,7 @@ hipError_t launch_wavefront(const DevScene& S, const FrameParams& P, const PathQ
 hipError_t launch_persist(const DevScene& S, const FrameParams& P, float4* result, DevCounters* ctr, unsigned int* next,
                           int n_blocks, bool count, hipStream_t st) {
   if (n_blocks <= 0) return hipSuccess;
-  hipError_t e = hipMemsetAsync(next, 0, sizeof(unsigned int), st);
+  hipError_t e = hipMemsetAsync(next, 0, kWorkShards * 32 * sizeof(unsigned int), st);
   if (e != hipSuccess) return e;
   size_t lds = stack_lds_bytes(P);
   if (count) hipLaunchKernelGGL(k_persist<true>, dim3(n_blocks), dim3(P.block_threads), lds, st, S, P, result, ctr, next);
@@ -958,7 +985,7 @@ hipError_t launch_sched(const DevScene& S, const FrameParams& P, float4* result,
                         int n_blocks, bool count, hipStream_t st) {
   if (n_blocks <= 0) return hipSuccess;
   if (P.block_threads != 64) return hipErrorInvalidValue;     // k_sched is built for one wave per workgroup (launch bounds 64, 5 waves/SIMD)
-  hipError_t e = hipMemsetAsync(next, 0, sizeof(unsigned int), st);
+  hipError_t e = hipMemsetAsync(next, 0, kWorkShards * 32 * sizeof(unsigned int), st);
   if (e != hipSuccess) return e;
   size_t lds = stack_lds_bytes(P);
   if (count) hipLaunchKernelGGL(k_sched<true>, dim3(n_blocks), dim3(P.block_threads), lds, st, S, P, result, ctr, next);

@@ -58,6 +58,7 @@ struct FrameParams {
   unsigned int watchdog_steps;  // cap on traversal trips per scheduled BLAS phase: a few times (nodes + leaves) of the scene
 };
 
+static constexpr unsigned int kWorkShards = 64;   // work counters of the persistent kernels (power of two), 128 B apart
 static constexpr int kCounterShards = 256;   // power of two; a block adds to shard blockIdx & (N-1)
 struct alignas(128) DevCounters {            // one shard = one 128-byte line of 64-bit counters
   unsigned long long rays, tlas_nodes, blas_nodes, tri_tests, sphere_tests;
