@@ -5,21 +5,34 @@ from unityraytracer_amd import Context, RayTraceMaster, scenes, _lib
 ctx = Context(0)
 lib = _lib.load()
 lib.urt_debug_read_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
-for (w, h, b) in ((1920, 1080, 8), (3840, 2160, 8)):
+import itertools
+for (w, h, b), wpc in itertools.product(((1920, 1080, 8), (3840, 2160, 8)), (4, 16)):
     sc = scenes.config3(w, h); sc.num_bounces = b
-    ctx.set_option("kernel_mode", 3)
+    ctx.set_option("kernel_mode", 3); ctx.set_option("waves_per_cu", wpc)
+    print(f"--- waves/CU {wpc}")
     m = RayTraceMaster(ctx, sc)
+    nw = 8192
     for _ in range(3): m.OnRenderImage()
     ctx.synchronize()
-    nw = 4096
-    st = np.zeros((nw, 16), np.uint64)
-    lib.urt_debug_read_stamps(ctx._h, st.ctypes.data_as(C.c_void_p), nw * 16)
+    junk = np.zeros((nw, 32), np.uint64); lib.urt_debug_read_stamps(ctx._h, junk.ctypes.data_as(C.c_void_p), nw * 32)   # clears
+    m.OnRenderImage(); ctx.synchronize()
+    st = np.zeros((nw, 32), np.uint64)
+    lib.urt_debug_read_stamps(ctx._h, st.ctypes.data_as(C.c_void_p), nw * 32)
     t = st[:, 0:4].astype(np.float64) / 100.0; lanes = st[:, 4:8].astype(np.float64); trips = st[:, 8:12].astype(np.float64)
     life = (st[:, 13] - st[:, 12]).astype(np.float64) / 100.0
-    end = (st[:, 13] - st[:, 12].min()).astype(np.float64) / 100.0
+    ok = st[:, 13] > 0
+    end = (st[:, 13].astype(np.float64) - float(st[ok, 12].min())) / 100.0
+    st, t, lanes, trips, life, end = st[ok], t[ok], lanes[ok], trips[ok], life[ok], end[ok]
+    t0 = st[:, 12].min()
+    dry = (st[:, 14].astype(np.float64) - float(t0)) / 100.0
+    start = (st[:, 12] - t0).astype(np.float64) / 100.0
+    print(f"   waves {ok.sum()}: start p50 {np.median(start):.0f} max {start.max():.0f} us; work ran dry (per wave) p10 {np.percentile(dry, 10):.0f} p50 {np.median(dry):.0f} max {dry.max():.0f} us; "
+          f"end p10 {np.percentile(end, 10):.0f} p50 {np.median(end):.0f} p90 {np.percentile(end, 90):.0f} p99 {np.percentile(end, 99):.0f} max {end.max():.0f} us")
     names = ["FRONT", "BLAS", "SHADE"]
     print(f"{w}x{h} b={b}: wave lifetime mean {life.mean():.0f} us, end p50 {np.median(end):.0f} p90 {np.percentile(end, 90):.0f} max {end.max():.0f} us")
     for q in range(3):
         print(f"   {names[q]:5s}: {t[:, q].sum() / life.sum() * 100:5.1f} % of wave time, {trips[:, q].mean():7.1f} trips/wave, {lanes[:, q].sum() / max(1, trips[:, q].sum()):5.1f} lanes/trip, {t[:, q].sum() / max(1, trips[:, q].sum()):7.2f} us/trip")
     print(f"   BLAS inner: {trips[:, 3].mean():8.1f} steps/wave, {lanes[:, 3].sum() / max(1, trips[:, 3].sum()):5.1f} active lanes/step, {t[:, 1].sum() / max(1, trips[:, 3].sum()) * 1000:7.1f} ns/step")
+    dbg = st[:, 16:21].astype(np.float64); cyc_per_us = (st[:, 15].astype(np.float64) / np.maximum(life, 1e-9)).mean()
+    print(f"   memtime ticks/us {cyc_per_us:.0f}; node steps/wave {dbg[:,0].mean():.0f}: load wait {dbg[:,1].sum()/dbg[:,0].sum()/cyc_per_us*1000:.0f} ns + rest {dbg[:,2].sum()/dbg[:,0].sum()/cyc_per_us*1000:.0f} ns; leaf steps/wave {dbg[:,3].mean():.0f}: {dbg[:,4].sum()/max(1,dbg[:,3].sum())/cyc_per_us*1000:.0f} ns each")
     m.OnDisable()

@@ -43,7 +43,7 @@ def oracle_for(scene, use_product_blas=True):
     return o
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
 def test_mixed_scene_bit_exact(gpu_ctx, mode):
     sc = scenes.mixed_test_scene(200, 120)           # ragged: not a multiple of 8
     o = oracle_for(sc)
@@ -54,7 +54,7 @@ def test_mixed_scene_bit_exact(gpu_ctx, mode):
         assert gc[k] == oc[k], (k, gc[k], oc[k])
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
 def test_config1_spheres_bit_exact(gpu_ctx, mode):
     sc = scenes.config1()
     ref = pyoracle.Oracle(sc).render(mode=0, threads=8)

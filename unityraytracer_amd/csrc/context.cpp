@@ -88,7 +88,8 @@ struct urt_context {
   float trace_ms = 0;
 
   int opt_count_stats = 0, opt_time_dispatch = 0, opt_kernel_mode = 3;
-  int opt_block_threads = 64, opt_xcd_run = 1, opt_refill_min = 48, opt_waves_per_cu = 0 /* auto */, opt_blas_min = 16, opt_blas_exit = 8;
+  int opt_block_threads = 64, opt_xcd_run = 1, opt_refill_min = 32, opt_waves_per_cu = 0 /* auto */, opt_blas_min = 28, opt_blas_exit = 6;
+  int opt_pool_k = 2, opt_pool_refill = 32, opt_pool_blas_min = 48, opt_pool_blas_exit = 8, opt_pool_inloop = 16, opt_pool_other_min = 24;   // kernel_mode 4
 };
 
 namespace {
@@ -348,18 +349,29 @@ int do_dispatch(urt_context* ctx, int kernel, int gx, int gy, int gz, int first_
     if (mode == 3) P.block_threads = 64;                       // one wave per workgroup: independent scheduling, 5 waves/SIMD
     int waves_per_block = P.block_threads / 64;
     long want = ((long)P.tiles_x * P.n_strips + waves_per_block - 1) / waves_per_block;
-    // resident waves per CU: small frames are bound by the latency chain of their last paths and want few, fat waves;
-    // large frames are throughput-bound and want every wave slot the registers allow (measured: 1080p best at 12,
-    // 2160p at 20).  auto = about 10 tiles of work per wave, clamped to [8, 20].
+    // resident waves per CU: every slot the registers allow (k_sched: 96 VGPRs -> 5 waves/SIMD = 20 per CU).  While the
+    // frame's work counter was one address, fewer and fatter waves were faster at 1080p (12 per CU); since it is sharded
+    // (kernels.hip wave_fetch_pixels) the full 20 win at every frame size measured (profiles/README.md).
     int wpc = ctx->opt_waves_per_cu;
-    if (wpc <= 0) {
-      long tiles = (long)P.tiles_x * P.n_strips;
-      wpc = (int)std::max(8L, std::min(20L, tiles / ((long)ctx->n_cus * 10)));
-    }
+    if (wpc <= 0) wpc = 20;
     long resident = (long)ctx->n_cus * wpc / waves_per_block;
     int nb = (int)std::max(1L, std::min(want, resident));
     le = mode == 2 ? launch_persist(S, P, res->dev, ctx->d_counters, ctx->d_next, nb, count, ctx->stream)
                    : launch_sched(S, P, res->dev, ctx->d_counters, ctx->d_next, nb, count, ctx->stream);
+  } else if (mode == 4) {
+    // one wave per workgroup; residency is bounded by the LDS one wave's path pool takes (kernels.hip k_pool)
+    P.block_threads = 64;
+    P.refill_min = ctx->opt_pool_refill; P.blas_min = ctx->opt_pool_blas_min; P.blas_exit = ctx->opt_pool_blas_exit;
+    P.pool_inloop = ctx->opt_pool_inloop; P.pool_other_min = ctx->opt_pool_other_min;
+    int k = ctx->opt_pool_k;
+    size_t lds = pool_lds_bytes(P, k);
+    while (k > 1 && lds > 160 * 1024) { k--; lds = pool_lds_bytes(P, k); }
+    if (lds > 160 * 1024) return fail(ctx, URT_ERR_OUT_OF_MEMORY, "kernel_mode 4: the scene's traversal stacks do not fit the LDS of one CU; use kernel_mode 3");
+    int fit = (int)std::max<size_t>(1, (160 * 1024) / lds);
+    int wpc = ctx->opt_waves_per_cu > 0 ? ctx->opt_waves_per_cu : fit;
+    long want = ((long)P.tiles_x * P.n_strips * 64 + 64L * k - 1) / (64L * k);
+    int nb = (int)std::max(1L, std::min(want, (long)ctx->n_cus * wpc));
+    le = launch_pool(S, P, res->dev, ctx->d_counters, ctx->d_next, nb, k, count, ctx->stream);
   } else le = launch_mega(S, P, res->dev, ctx->d_counters, count, ctx->stream);
   if (ctx->opt_time_dispatch) {
     (void)hipEventRecord(e1, ctx->stream);
@@ -402,6 +414,7 @@ int urt_context_create(int device, urt_context** out_ctx) {
   e = hipMalloc((void**)&ctx->d_counters, sizeof(DevCounters) * kCounterShards);
   if (e == hipSuccess) e = hipMemset(ctx->d_counters, 0, sizeof(DevCounters) * kCounterShards);
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_next, kWorkShards * 128 + 65536 * 16 * sizeof(unsigned long long));   // work-counter shards; the rest: diagnostic stamps (URT_STAMPS builds)
+  if (e == hipSuccess) e = hipMemset(ctx->d_next, 0, kWorkShards * 128 + 65536 * 16 * sizeof(unsigned long long));
   if (e == hipSuccess) { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n > 0) ctx->n_cus = n; }
   if (e != hipSuccess) { (void)hipStreamDestroy(ctx->own_stream); delete ctx; return fail(nullptr, URT_ERR_HIP, std::string("counter allocation: ") + hipGetErrorString(e)); }
   *out_ctx = ctx;
@@ -695,7 +708,7 @@ int urt_set_option(urt_context* ctx, const char* name, int value) {
   if (std::strcmp(name, "count_stats") == 0) ctx->opt_count_stats = value ? 1 : 0;
   else if (std::strcmp(name, "time_dispatch") == 0) ctx->opt_time_dispatch = value ? 1 : 0;
   else if (std::strcmp(name, "kernel_mode") == 0) {
-    if (value < 0 || value > 3) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "kernel_mode must be 0..3");
+    if (value < 0 || value > 4) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "kernel_mode must be 0..4");
     ctx->opt_kernel_mode = value;
   } else if (std::strcmp(name, "block_threads") == 0) {
     if (value != 64 && value != 128 && value != 256) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "block_threads must be 64, 128 or 256");
@@ -716,6 +729,24 @@ int urt_set_option(urt_context* ctx, const char* name, int value) {
   } else if (std::strcmp(name, "waves_per_cu") == 0) {
     if (value < 0 || value > 32) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "waves_per_cu must be in [0, 32] (0 = auto)");
     ctx->opt_waves_per_cu = value;
+  } else if (std::strcmp(name, "pool_k") == 0) {
+    if (value < 1 || value > 4) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "pool_k must be in [1, 4]");
+    ctx->opt_pool_k = value;
+  } else if (std::strcmp(name, "pool_refill") == 0) {
+    if (value < 1 || value > 256) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "pool_refill must be in [1, 256]");
+    ctx->opt_pool_refill = value;
+  } else if (std::strcmp(name, "pool_blas_min") == 0) {
+    if (value < 1 || value > 256) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "pool_blas_min must be in [1, 256]");
+    ctx->opt_pool_blas_min = value;
+  } else if (std::strcmp(name, "pool_blas_exit") == 0) {
+    if (value < 1 || value > 64) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "pool_blas_exit must be in [1, 64]");
+    ctx->opt_pool_blas_exit = value;
+  } else if (std::strcmp(name, "pool_other_min") == 0) {
+    if (value < 1 || value > 64) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "pool_other_min must be in [1, 64]");
+    ctx->opt_pool_other_min = value;
+  } else if (std::strcmp(name, "pool_inloop") == 0) {
+    if (value < 1 || value > 64) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "pool_inloop must be in [1, 64]");
+    ctx->opt_pool_inloop = value;
   } else if (std::strcmp(name, "xcd_run") == 0) {
     if (value < 1 || value > 4096) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "xcd_run must be in [1, 4096]");
     ctx->opt_xcd_run = value;
@@ -760,7 +791,9 @@ int urt_reset_counters(urt_context* ctx) {
 /* diagnostic builds only: per-wave (start, pool-exhausted, end, iters<<32|fetches) of the last persistent launch */
 __attribute__((visibility("default"))) int urt_debug_read_stamps(urt_context* ctx, unsigned long long* out, int n_waves) {
   (void)hipStreamSynchronize(ctx->stream);
-  return (int)hipMemcpy(out, (char*)ctx->d_next + kWorkShards * 128, (size_t)n_waves * sizeof(unsigned long long), hipMemcpyDeviceToHost);   // n_waves = number of u64 words
+  hipError_t e = hipMemcpy(out, (char*)ctx->d_next + kWorkShards * 128, (size_t)n_waves * sizeof(unsigned long long), hipMemcpyDeviceToHost);   // n_waves = number of u64 words
+  (void)hipMemset((char*)ctx->d_next + kWorkShards * 128, 0, 65536 * 16 * sizeof(unsigned long long));
+  return (int)e;
 }
 #endif
 

@@ -16,6 +16,10 @@ hipError_t launch_persist(const DevScene& S, const FrameParams& P, float4* resul
 // mode 3: persistent waves whose lanes are scheduled by phase (FRONT / BLAS / SHADE) inside the wave
 hipError_t launch_sched(const DevScene& S, const FrameParams& P, float4* result, DevCounters* ctr, unsigned int* next,
                         int n_blocks, bool count, hipStream_t st);
+// mode 4: persistent waves over a pool of 64*k paths per wave kept in LDS, phases run on compacted lanes
+hipError_t launch_pool(const DevScene& S, const FrameParams& P, float4* result, DevCounters* ctr, unsigned int* next,
+                       int n_blocks, int k, bool count, hipStream_t st);
+size_t pool_lds_bytes(const FrameParams& P, int k);   // dynamic LDS of one wave (= one workgroup) of mode 4
 // AdditionShader blend (AS:9,39-41)
 hipError_t launch_blit_add(const float4* src, float4* dst, size_t n_pixels, float sample, hipStream_t st);
 // strips <-> dense buffer

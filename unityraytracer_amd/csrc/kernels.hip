@@ -145,10 +145,14 @@ __device__ __forceinline__ int32_t blas_pop(int* stk, int& sp) {
 // push the other; returns the next cursor.
 template <bool COUNT>
 __device__ __forceinline__ int32_t blas_node_step(const DevScene& S, int32_t cur, const BlasRay& R, float tbest, int* stk, int& sp,
-                                                  LocalCounters& lc) {
+                                                  LocalCounters& lc, unsigned long long* dbg_loaded = nullptr) {
   if (COUNT) lc.blas_nodes++;
   const float4* n = S.blas_nodes + 4 * (size_t)cur;
   float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
+  if (dbg_loaded) {                      // diagnostic builds: when did the node arrive?
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(q0.x), "+v"(q1.x), "+v"(q2.x), "+v"(q3.x) : : "memory");
+    *dbg_loaded = __builtin_amdgcn_s_memtime();
+  }
   // child 0: min (q0.x q0.y q0.z) max (q0.w q1.x q1.y)
   float a1x = f_fma(q0.x, R.idir.x, R.nop.x), a2x = f_fma(q0.w, R.idir.x, R.nom.x);
   float a1y = f_fma(q0.y, R.idir.y, R.nop.y), a2y = f_fma(q1.x, R.idir.y, R.nom.y);
@@ -327,17 +331,24 @@ __device__ __forceinline__ bool shade(const DevScene& S, const HitRec& h, v3& o,
     specChance /= sum;
     diffChance /= sum;
     float roulette = rand_next(seed, px, py);
-    if (roulette < specChance) {
-      float alpha = f_pow(1000.0f, smooth * smooth);
+    // RS:399-418.  The specular and the diffuse branch both end in SampleHemisphere: lanes of one wave take either, so the
+    // branch-specific inputs (lobe axis, Phong alpha) are selected first and the long common part runs ONCE for both kinds
+    // of lane.  Per lane the operations and their order are those of the two-branch form.
+    bool is_spec = roulette < specChance;
+    bool is_diff = !is_spec && diffChance > 0 && roulette < specChance + diffChance;
+    if (is_spec || is_diff) {
+      float alpha = 1.0f;
+      v3 axis = n;
+      if (is_spec) { alpha = f_pow(1000.0f, smooth * smooth); axis = reflect(d, n); }
       o = madd(0.001f, n, pos);
-      d = sample_hemisphere(reflect(d, n), alpha, seed, px, py);
-      float f = (alpha + 2) / (alpha + 1);
-      float sd = f_saturate(dot(n, d) * f);
-      energy = energy * (((1.0f / specChance) * spec) * sd);
-    } else if (diffChance > 0 && roulette < specChance + diffChance) {
-      o = madd(0.001f, n, pos);
-      d = sample_hemisphere(n, 1.0f, seed, px, py);
-      energy = energy * ((1.0f / diffChance) * albedo);
+      d = sample_hemisphere(axis, alpha, seed, px, py);
+      if (is_spec) {
+        float f = (alpha + 2) / (alpha + 1);
+        float sd = f_saturate(dot(n, d) * f);
+        energy = energy * (((1.0f / specChance) * spec) * sd);
+      } else {
+        energy = energy * ((1.0f / diffChance) * albedo);
+      }
     } else {
       energy = mk3(0, 0, 0);
     }
@@ -487,8 +498,18 @@ struct WorkCursor {
 };
 static_assert(kWorkShards == 64, "the dry-shard probe reads one counter per lane");
 
-__device__ __forceinline__ unsigned int shard_slots(unsigned int ntiles, unsigned int shard) {   // slots owned by a shard
-  return ((ntiles + kWorkShards - 1u - shard) / kWorkShards) * 64u;
+// Tiles are dealt to the shards in RUNS of G = P.xcd_run consecutive tiles (run r belongs to shard r % kWorkShards).  G = 1
+// interleaves single tiles; a large G gives every shard contiguous image bands, and because workgroup b runs on XCD b % 8
+// and starts on shard b % kWorkShards, each XCD's L2 then serves a few bands of the image instead of all of it.
+__device__ __forceinline__ unsigned int shard_slots(unsigned int ntiles, unsigned int shard, unsigned int G) {   // slots owned by a shard
+  unsigned int cycle = kWorkShards * G;
+  unsigned int full = ntiles / cycle, rem = ntiles - full * cycle;
+  unsigned int extra = rem > shard * G ? min(rem - shard * G, G) : 0u;
+  return (full * G + extra) * 64u;
+}
+__device__ __forceinline__ unsigned int shard_tile(unsigned int shard, unsigned int q, unsigned int G) {   // q-th tile of a shard
+  unsigned int run = q / G;
+  return (run * kWorkShards + shard) * G + (q - run * G);
 }
 
 // slot -> pixel; false for slots that fall outside the dispatched region (ragged right/top edge)
@@ -505,14 +526,15 @@ __device__ __forceinline__ bool wave_fetch_pixels(const FrameParams& P, unsigned
                                                   unsigned int ntiles, WorkCursor& wc, bool& exhausted, int& x, int& y) {
   const int lane = threadIdx.x & 63;
   unsigned int n = (unsigned int)__popcll(want);
-  unsigned int own = shard_slots(ntiles, wc.shard);
+  const unsigned int G = (unsigned int)P.xcd_run;
+  unsigned int own = shard_slots(ntiles, wc.shard, G);
   unsigned int base = 0;
   if (lane == 0) base = atomicAdd(next + wc.shard * 32u, n);
   base = __shfl(base, 0, 64);
   unsigned int shard = wc.shard;
   if (base + n >= own) {   // this shard is (now) dry: every lane looks at one counter, the wave moves to the next shard with work
     unsigned int seen = __hip_atomic_load(next + lane * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned long long avail = __ballot(seen < shard_slots(ntiles, (unsigned int)lane)) & ~(1ull << shard);
+    unsigned long long avail = __ballot(seen < shard_slots(ntiles, (unsigned int)lane, G)) & ~(1ull << shard);
     if (!avail) {
       exhausted = true;    // counters only grow, so this is final
     } else {
@@ -522,7 +544,7 @@ __device__ __forceinline__ bool wave_fetch_pixels(const FrameParams& P, unsigned
   }
   unsigned int local = base + (unsigned int)__popcll(want & ((1ull << lane) - 1ull));
   if (!mine || local >= own) return false;
-  return slot_pixel(P, (local >> 6) * kWorkShards + shard, local & 63u, x, y);
+  return slot_pixel(P, shard_tile(shard, local >> 6, G), local & 63u, x, y);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -601,6 +623,67 @@ __global__ __launch_bounds__(256) void k_persist(DevScene S, FrameParams P, floa
   flush_counters<COUNT>(lc, ctr);
 }
 
+// Trace() (RS:364-383) cut at its triangle-BVH visits, for the phase-scheduled kernels: runs from the start of Trace
+// (`fresh`) or from the return of a triangle-BVH visit up to the NEXT MeshObject whose triangle BVH must be walked
+// (returns true, `cur` = its root) or to the end of Trace (returns false; `best` is final).  `check`/`seen` are the
+// object-level walk's stack height and its never-reset `tests` flag (RS:296-297, A.5); the object-level stack entry e of
+// this path is tl[e * stride].
+template <bool COUNT>
+__device__ __forceinline__ bool trace_front(const DevScene& S, bool fresh, v3 o, v3 d, HitRec& best, int& check, bool& seen,
+                                            int* tl, int stride, int32_t& cur, LocalCounters& lc) {
+  if (fresh) {
+    lc.rays++;
+    best.t = URT_INF; best.kind = 0; best.id = 0; best.u = 0; best.v = 0;
+    float t = -o.y / d.y;                                   // IntersectGroundPlane RS:156-172
+    if (t > 0 && t < best.t) { best.t = t; best.kind = 1; }
+    check = 0; seen = false;
+    if (S.n_meshes > 0) { check = 1; tl[0] = 0; }
+  }
+  v3 rcp = mk3(1.0f / (d.x + kEPSILON), 1.0f / (d.y + kEPSILON), 1.0f / (d.z + kEPSILON));
+  while (check > 0) {                                        // IntersectMeshBVH RS:294-326
+    check--;
+    int bi = tl[check * stride];
+    bool hit = false; int index = -1;
+    if (bi < S.n_mesh_tlas) {
+      if (COUNT) lc.tlas_nodes++;
+      float4 a = S.mesh_tlas[2 * bi], b = S.mesh_tlas[2 * bi + 1];
+      index = as_int(a.w);
+      hit = tlas_slab(a, b, o, rcp);
+    }
+    if (hit) {
+      if (index < 0) { tl[check * stride] = bi * 2 + 1; check++; tl[check * stride] = bi * 2 + 2; check++; }
+      else seen = true;
+    }
+    if (seen && index >= 0 && index < S.n_meshes) {
+      int32_t root = S.mesh_root[index];
+      if (root < 0 && root != kBlasDone) {               // a mesh of <= 8 triangles is one leaf: test it here, no phase switch
+        int bi_local = -1;
+        test_leaf<COUNT>(S, root, o, d, best, bi_local, lc);
+      } else if (root != kEmptyMeshRoot) { cur = root; return true; }
+    }
+  }
+  if (S.n_spheres > 0) {                                   // IntersectSphereBVH RS:329-361
+    int c2 = 1; tl[0] = 0; bool seen2 = false;
+    while (c2 > 0) {
+      c2--;
+      int bi = tl[c2 * stride];
+      bool hit = false; int index = -1;
+      if (bi < S.n_sphere_tlas) {
+        if (COUNT) lc.tlas_nodes++;
+        float4 a = S.sphere_tlas[2 * bi], b = S.sphere_tlas[2 * bi + 1];
+        index = as_int(a.w);
+        hit = tlas_slab(a, b, o, rcp);
+      }
+      if (hit) {
+        if (index < 0) { tl[c2 * stride] = bi * 2 + 1; c2++; tl[c2 * stride] = bi * 2 + 2; c2++; }
+        else seen2 = true;
+      }
+      if (seen2 && index >= 0 && index < S.n_spheres) intersect_sphere<COUNT>(S, index, o, d, best, lc);
+    }
+  }
+  return false;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // mode 3: persistent waves, lanes SCHEDULED BY PHASE inside the wave.
 // Measured on mode 2 (profiles/README.md): after the first bounce only a minority of a wave's lanes needs
@@ -618,8 +701,11 @@ __global__ __launch_bounds__(256) void k_persist(DevScene S, FrameParams P, floa
 enum : int { ST_DEAD = 0, ST_FRONT = 1, ST_RESUME = 2, ST_BLAS = 3, ST_SHADE = 4 };
 static constexpr unsigned int kWatchdogIters = 1u << 24;    // scheduler trips per wave (a frame needs ~1e3-1e5)
 
+#ifndef URT_SCHED_OCC
+#define URT_SCHED_OCC 5
+#endif
 template <bool COUNT>
-__global__ __launch_bounds__(64, 5) void k_sched(DevScene S, FrameParams P, float4* __restrict__ result, DevCounters* ctr,
+__global__ __launch_bounds__(64, URT_SCHED_OCC) void k_sched(DevScene S, FrameParams P, float4* __restrict__ result, DevCounters* ctr,
                                                unsigned int* __restrict__ next) {
   int *tl, *bl;
   lane_stacks(P, tl, bl);
@@ -640,11 +726,15 @@ __global__ __launch_bounds__(64, 5) void k_sched(DevScene S, FrameParams P, floa
   bool watchdog = false;
 #ifdef URT_STAMPS
   unsigned long long ph_t[4] = {0, 0, 0, 0}, ph_lanes[4] = {0, 0, 0, 0}, ph_trips[4] = {0, 0, 0, 0};   // FRONT, BLAS, SHADE, blas inner trips
-  unsigned long long t_begin = wall_clock64();
+  unsigned long long t_begin = wall_clock64(), t_dry = 0, dbg[5] = {0, 0, 0, 0, 0};
+  unsigned long long c_begin = __builtin_amdgcn_s_memtime();
 #endif
 
   for (;;) {
     if (watchdog) break;
+#ifdef URT_STAMPS
+    if (exhausted && !t_dry) t_dry = wall_clock64();
+#endif
     unsigned long long mD = __ballot(st == ST_DEAD);
     int nD = __popcll(mD);
     int nB = __popcll(__ballot(st == ST_BLAS));
@@ -682,62 +772,8 @@ __global__ __launch_bounds__(64, 5) void k_sched(DevScene S, FrameParams P, floa
     if (phase == ST_FRONT) {
       // ---------------- FRONT / RESUME: Trace() up to the next triangle-BVH visit (RS:364-383) ----------------
       if (st == ST_FRONT || st == ST_RESUME) {
-        if (st == ST_FRONT) {
-          lc.rays++;
-          best.t = URT_INF; best.kind = 0; best.id = 0; best.u = 0; best.v = 0;
-          float t = -o.y / d.y;                                   // IntersectGroundPlane RS:156-172
-          if (t > 0 && t < best.t) { best.t = t; best.kind = 1; }
-          check = 0; seen = false;
-          if (S.n_meshes > 0) { check = 1; tl[0] = 0; }
-        }
-        v3 rcp = mk3(1.0f / (d.x + kEPSILON), 1.0f / (d.y + kEPSILON), 1.0f / (d.z + kEPSILON));
-        bool need_blas = false;
-        while (check > 0) {                                        // IntersectMeshBVH RS:294-326
-          check--;
-          int bi = tl[check * 64];
-          bool hit = false; int index = -1;
-          if (bi < S.n_mesh_tlas) {
-            if (COUNT) lc.tlas_nodes++;
-            float4 a = S.mesh_tlas[2 * bi], b = S.mesh_tlas[2 * bi + 1];
-            index = as_int(a.w);
-            hit = tlas_slab(a, b, o, rcp);
-          }
-          if (hit) {
-            if (index < 0) { tl[check * 64] = bi * 2 + 1; check++; tl[check * 64] = bi * 2 + 2; check++; }
-            else seen = true;
-          }
-          if (seen && index >= 0 && index < S.n_meshes) {
-            int32_t root = S.mesh_root[index];
-            if (root < 0 && root != kBlasDone) {               // a mesh of <= 8 triangles is one leaf: test it here, no phase switch
-              int bi_local = -1;
-              test_leaf<COUNT>(S, root, o, d, best, bi_local, lc);
-            } else if (root != kEmptyMeshRoot) { cur = root; sp = 0; best_i = -1; need_blas = true; break; }
-          }
-        }
-        if (need_blas) {
-          st = ST_BLAS;
-        } else {
-          if (S.n_spheres > 0) {                                   // IntersectSphereBVH RS:329-361
-            int c2 = 1; tl[0] = 0; bool seen2 = false;
-            while (c2 > 0) {
-              c2--;
-              int bi = tl[c2 * 64];
-              bool hit = false; int index = -1;
-              if (bi < S.n_sphere_tlas) {
-                if (COUNT) lc.tlas_nodes++;
-                float4 a = S.sphere_tlas[2 * bi], b = S.sphere_tlas[2 * bi + 1];
-                index = as_int(a.w);
-                hit = tlas_slab(a, b, o, rcp);
-              }
-              if (hit) {
-                if (index < 0) { tl[c2 * 64] = bi * 2 + 1; c2++; tl[c2 * 64] = bi * 2 + 2; c2++; }
-                else seen2 = true;
-              }
-              if (seen2 && index >= 0 && index < S.n_spheres) intersect_sphere<COUNT>(S, index, o, d, best, lc);
-            }
-          }
-          st = ST_SHADE;
-        }
+        if (trace_front<COUNT>(S, st == ST_FRONT, o, d, best, check, seen, tl, 64, cur, lc)) { sp = 0; best_i = -1; st = ST_BLAS; }
+        else st = ST_SHADE;
       }
     } else if (phase == ST_BLAS) {
       // ---------------- BLAS: triangle BVH of one MeshObject, resumable ----------------
@@ -757,15 +793,35 @@ __global__ __launch_bounds__(64, 5) void k_sched(DevScene S, FrameParams P, floa
         bool interior = active && cur >= 0;
         int nI = __popcll(__ballot(interior));
         int nL = __popcll(mA) - nI;
+#ifdef URT_STAMPS
+        unsigned long long tq0 = __builtin_amdgcn_s_memtime(), tq1 = tq0;
+        if (nI >= nL) {
+          if (interior) cur = blas_node_step<COUNT>(S, cur, R, best.t, bl, sp, lc, &tq1);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          unsigned long long tq2 = __builtin_amdgcn_s_memtime();
+          tq1 = __shfl(tq1, __ffsll((long long)__ballot(interior)) - 1, 64);
+          dbg[0]++; dbg[1] += tq1 - tq0; dbg[2] += tq2 - tq1;
+        } else {
+          if (active && !interior) {
+            test_leaf<COUNT>(S, cur, o, d, best, best_i, lc);
+            cur = blas_pop(bl, sp);
+          }
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+          dbg[3]++; dbg[4] += __builtin_amdgcn_s_memtime() - tq0;
+        }
+#else
         if (nI >= nL) {
           if (interior) cur = blas_node_step<COUNT>(S, cur, R, best.t, bl, sp, lc);
         } else if (active && !interior) {
           test_leaf<COUNT>(S, cur, o, d, best, best_i, lc);
           cur = blas_pop(bl, sp);
         }
+#endif
         active = mine && cur != kBlasDone;
       }
-      if (mine && cur == kBlasDone) st = ST_RESUME;               // back to the heap walk (RS:323-325 continues)
+      // back to the heap walk (RS:323-325 continues) — or, when nothing of Trace() is left to do (empty object-level stack and
+      // no spheres), straight to shading: saves the path one scheduling round trip per bounce
+      if (mine && cur == kBlasDone) st = (check == 0 && S.n_spheres == 0) ? ST_SHADE : ST_RESUME;
     } else {
       // ---------------- SHADE + bookkeeping of CSMain's loops (RS:444-468) ----------------
       if (st == ST_SHADE) {
@@ -794,12 +850,290 @@ __global__ __launch_bounds__(64, 5) void k_sched(DevScene S, FrameParams P, floa
 #ifdef URT_STAMPS
   if ((threadIdx.x & 63) == 0) {
     unsigned long long* sp_ = (unsigned long long*)(next + kWorkShards * 32);
-    size_t w = ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16;
+    size_t w = ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 32;
     for (int q = 0; q < 4; q++) { sp_[w + q] = ph_t[q]; sp_[w + 4 + q] = ph_lanes[q]; sp_[w + 8 + q] = ph_trips[q]; }
-    sp_[w + 12] = t_begin; sp_[w + 13] = wall_clock64();
+    sp_[w + 12] = t_begin; sp_[w + 13] = wall_clock64(); sp_[w + 14] = t_dry; sp_[w + 15] = __builtin_amdgcn_s_memtime() - c_begin;
+    for (int q = 0; q < 5; q++) sp_[w + 16 + q] = dbg[q];
   }
 #endif
   if (watchdog && (threadIdx.x & 63) == 0) atomicAdd(&ctr->watchdog, 1ull);
+  flush_counters<COUNT>(lc, ctr);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// mode 4: persistent waves over a POOL of paths (K x 64 path slots per wave, state in LDS).
+// Measured on mode 3 (profiles/README.md): a wave that owns exactly 64 paths runs its triangle-BVH phase with 16-20 active
+// lanes and its SHADE phase with ~30 — the paths of one wave are simply spread over the phases.  Every VALU instruction
+// costs 4 cycles whatever the number of active lanes, and the kernel is ~45 % VALU-issue bound, so idle lanes are the cost.
+// Here a wave owns NP = 64*K paths whose state (24 words, SoA [field][slot]) lives in LDS.  Each trip the wave takes a census
+// of the slot states, elects ONE phase, compacts up to 64 slots that are in that phase onto its lanes (ballot + prefix
+// popcount), loads what that phase needs, runs it, and stores the state back:
+//     FREE -> FRONT -> BLAS -> RESUME -> ... -> SHADE -> FRONT | FREE
+// The triangle-BVH phase keeps its 64 lanes fed from the list of waiting BLAS slots while it runs (a lane whose ray has
+// finished retires it and takes the next one), and yields when few lanes are left; a suspended traversal stays PINNED to
+// its lane, because its stack is the lane's ([entry][lane] in LDS), and resumes there.
+// Per-pixel arithmetic and operation order are those of modes 0-3 (same device functions): pixels are bit-identical.
+// ---------------------------------------------------------------------------------------------------
+enum : int { PS_FREE = 0, PS_FRONT = 1, PS_RESUME = 2, PS_BLAS = 3, PS_PINNED = 4, PS_SHADE = 5 };
+enum : int { F_PIX = 0, F_K, F_RAYI, F_SEED, F_OX, F_OY, F_OZ, F_DX, F_DY, F_DZ, F_EX, F_EY, F_EZ, F_RX, F_RY, F_RZ,
+             F_T, F_KINDID, F_U, F_V, F_CHECK, F_CUR, F_SP, F_BESTI, F_COUNT1,      // _numRays == 1: 24 words per path
+             F_AX = F_COUNT1, F_AY, F_AZ, F_COUNTN };                                // + resultAverage when _numRays > 1
+
+// Slots whose state is in [lo, hi], in slot order: list[] receives all of them (`total`), lane L gets the L-th or -1.
+template <int K>
+__device__ __forceinline__ int pool_select(const int* stt, int* list, int lo, int hi, int& total) {
+  const int lane = threadIdx.x & 63;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  int base = 0;
+#pragma unroll
+  for (int j = 0; j < K; j++) {
+    int slot = j * 64 + lane;
+    int v = stt[slot];
+    bool m = v >= lo && v <= hi;
+    unsigned long long b = __ballot(m);
+    if (m) list[base + __popcll(b & below)] = slot;
+    base += __popcll(b);
+  }
+  total = base;
+  __syncthreads();                 // one wave per workgroup: orders the LDS writes above before the reads below
+  return lane < total ? list[lane] : -1;
+}
+
+template <bool COUNT, int K>
+__global__ __launch_bounds__(64) void k_pool(DevScene S, FrameParams P, float4* __restrict__ result, DevCounters* ctr,
+                                             unsigned int* __restrict__ next) {
+  constexpr int NP = 64 * K;
+  extern __shared__ int lds[];
+  const int lane = threadIdx.x & 63;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  int* bl = lds + lane;                                // triangle-BVH stack of this LANE, entry e at bl[e * 64]
+  int* pin = lds + P.blas_stack * 64;                  // [64] slot whose suspended traversal owns the lane's stack, or -1
+  int* list = pin + 64;                                // [NP] compaction scratch
+  int* stt = list + NP;                                // [NP] slot state
+  int* pf = stt + NP;                                  // [fields][NP] path state
+  const bool multi = P.num_rays > 1;
+  int* tls = pf + (multi ? F_COUNTN : F_COUNT1) * NP;  // [tlas_stack][NP] object-level stack of each SLOT
+#define PF(field, slot) pf[(field) * NP + (slot)]
+#define PFf(field, slot) as_float(pf[(field) * NP + (slot)])
+#define PFset(field, slot, val) pf[(field) * NP + (slot)] = as_int(val)
+  pin[lane] = -1;
+#pragma unroll
+  for (int j = 0; j < K; j++) stt[j * 64 + lane] = PS_FREE;
+  LocalCounters lc;
+  const unsigned int ntiles = (unsigned int)(P.tiles_x * P.n_strips);
+  WorkCursor wc; wc.shard = blockIdx.x & (kWorkShards - 1u);
+  bool exhausted = false, watchdog = false;
+  unsigned int wave_iters = 0;
+#ifdef URT_STAMPS
+  unsigned long long ph_t[4] = {0, 0, 0, 0}, ph_lanes[5] = {0, 0, 0, 0, 0}, ph_trips[5] = {0, 0, 0, 0, 0};   // FRONT, BLAS, SHADE, blas inner, refill
+  unsigned long long t_begin = wall_clock64(), t_dry = 0;
+#endif
+
+  for (;;) {
+    if (watchdog) break;
+#ifdef URT_STAMPS
+    if (exhausted && !t_dry) t_dry = wall_clock64();
+#endif
+    __syncthreads();                                   // slot states written by other lanes during the last trip
+    int nFree = 0, nFront = 0, nNew = 0, nPin = 0, nShade = 0;
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+      int v = stt[j * 64 + lane];
+      nFree += __popcll(__ballot(v == PS_FREE));
+      nFront += __popcll(__ballot(v == PS_FRONT || v == PS_RESUME));
+      nNew += __popcll(__ballot(v == PS_BLAS));
+      nPin += __popcll(__ballot(v == PS_PINNED));
+      nShade += __popcll(__ballot(v == PS_SHADE));
+    }
+    if (++wave_iters > kWatchdogIters) { watchdog = true; break; }   // an exit every wave reaches, whatever the data
+    const int busy = nFront + nNew + nPin + nShade;
+    // ---- phase election ----
+    // The triangle-BVH phase is the expensive one (hundreds of dependent steps per quantum, each costing the same whether
+    // 8 or 64 lanes take part), so it waits until `blas_min` rays are queued for it; meanwhile the cheap phases run whenever
+    // they have `pool_other_min` lanes of work, and free slots are refilled with new pixels.  Only when nothing reaches its
+    // threshold does the fullest phase run.
+    const int nB = nNew + nPin;
+    const bool can_fetch = !exhausted && nFree > 0;
+    int phase;
+    if (nB >= P.blas_min) phase = PS_BLAS;
+    else if (can_fetch && nFree >= P.refill_min) phase = PS_FREE;
+    else if (nShade >= P.pool_other_min && nShade >= nFront) phase = PS_SHADE;
+    else if (nFront >= P.pool_other_min) phase = PS_FRONT;
+    else if (nShade >= P.pool_other_min) phase = PS_SHADE;
+    else if (can_fetch) phase = PS_FREE;
+    else if (busy == 0) break;                           // nothing in the pool and no work left to fetch
+    else if (nB >= nShade && nB >= nFront) phase = PS_BLAS;
+    else if (nShade >= nFront) phase = PS_SHADE;
+    else phase = PS_FRONT;
+
+    if (phase == PS_FREE) {
+      // ---- new pixels into free slots (one atomic per refill) ----
+      int total;
+      int mine = pool_select<K>(stt, list, PS_FREE, PS_FREE, total);
+#ifdef URT_STAMPS
+      ph_trips[4]++; ph_lanes[4] += (unsigned long long)min(total, 64);
+#endif
+      int x = 0, y = 0;
+      if (wave_fetch_pixels(P, __ballot(mine >= 0), mine >= 0, next, ntiles, wc, exhausted, x, y)) {
+        float seed = P.seed;
+        v3 o, d;
+        camera_ray<kPOffAfterScene>(P, x, y, seed, o, d);
+        PF(F_PIX, mine) = x | (y << 16); PF(F_K, mine) = 0; PF(F_RAYI, mine) = 0; PFset(F_SEED, mine, seed);
+        PFset(F_OX, mine, o.x); PFset(F_OY, mine, o.y); PFset(F_OZ, mine, o.z);
+        PFset(F_DX, mine, d.x); PFset(F_DY, mine, d.y); PFset(F_DZ, mine, d.z);
+        PFset(F_EX, mine, 1.0f); PFset(F_EY, mine, 1.0f); PFset(F_EZ, mine, 1.0f);
+        PFset(F_RX, mine, 0.0f); PFset(F_RY, mine, 0.0f); PFset(F_RZ, mine, 0.0f);
+        if (multi) { PFset(F_AX, mine, 0.0f); PFset(F_AY, mine, 0.0f); PFset(F_AZ, mine, 0.0f); }
+        stt[mine] = PS_FRONT;
+      }
+      continue;
+    }
+#ifdef URT_STAMPS
+    unsigned long long t_ph = wall_clock64();
+    int ph_id = phase == PS_FRONT ? 0 : phase == PS_BLAS ? 1 : 2;
+    ph_lanes[ph_id] += (unsigned long long)min(64, phase == PS_FRONT ? nFront : phase == PS_BLAS ? nB : nShade);
+    ph_trips[ph_id]++;
+#endif
+
+    if (phase == PS_FRONT) {
+      // ---------------- FRONT / RESUME: Trace() up to the next triangle-BVH visit (RS:364-383) ----------------
+      int total;
+      int mine = pool_select<K>(stt, list, PS_FRONT, PS_RESUME, total);
+      if (mine >= 0) {
+        bool fresh = stt[mine] == PS_FRONT;
+        v3 o = mk3(PFf(F_OX, mine), PFf(F_OY, mine), PFf(F_OZ, mine)), d = mk3(PFf(F_DX, mine), PFf(F_DY, mine), PFf(F_DZ, mine));
+        HitRec best; best.t = URT_INF; best.kind = 0; best.id = 0; best.u = 0; best.v = 0;
+        int check = 0; bool seen = false;
+        if (!fresh) {
+          int ki = PF(F_KINDID, mine), cs = PF(F_CHECK, mine);
+          best.t = PFf(F_T, mine); best.kind = ki & 7; best.id = ki >> 3; best.u = PFf(F_U, mine); best.v = PFf(F_V, mine);
+          check = cs >> 1; seen = (cs & 1) != 0;
+        }
+        int32_t cur = kBlasDone;
+        bool need = trace_front<COUNT>(S, fresh, o, d, best, check, seen, tls + mine, NP, cur, lc);
+        PFset(F_T, mine, best.t); PF(F_KINDID, mine) = (best.id << 3) | best.kind; PFset(F_U, mine, best.u); PFset(F_V, mine, best.v);
+        PF(F_CHECK, mine) = (check << 1) | (seen ? 1 : 0);
+        if (need) { PF(F_CUR, mine) = cur; PF(F_SP, mine) = 0; PF(F_BESTI, mine) = -1; stt[mine] = PS_BLAS; }
+        else stt[mine] = PS_SHADE;
+      }
+    } else if (phase == PS_BLAS) {
+      // ---------------- BLAS: triangle BVH of one MeshObject per ray; lanes are re-fed from the waiting list ----------------
+      int total;
+      (void)pool_select<K>(stt, list, PS_BLAS, PS_BLAS, total);     // list[0, total) = the waiting rays, in slot order
+      int taken = 0;
+      int mys = pin[lane];                                          // a suspended traversal resumes on the lane that holds its stack
+      const int n0 = min(64, nB);
+      const int exit_below = (nShade + nFront > 0 || can_fetch) ? min(P.blas_exit, n0) : 1;
+      v3 o = mk3(0, 0, 0), d = mk3(0, 0, 1);
+      HitRec best; best.t = URT_INF; best.kind = 0; best.id = 0; best.u = 0; best.v = 0;
+      int32_t cur = kBlasDone; int sp = 0, best_i = -1;
+      bool load = mys >= 0, first = true;
+      BlasRay R = blas_ray(o, d);
+      unsigned long long steps = 0;
+      const unsigned long long step_cap = (unsigned long long)P.watchdog_steps * 64ull;   // between two re-feeds
+      for (;;) {
+        unsigned long long mA = __ballot(mys >= 0);
+        int nA = __popcll(mA);
+        if (taken < total && (first || 64 - nA >= P.pool_inloop || nA < exit_below)) {     // feed the idle lanes
+          int r = __popcll(~mA & below);
+          if (mys < 0 && taken + r < total) { mys = list[taken + r]; load = true; }
+          taken = min(total, taken + 64 - nA);
+          steps = 0;
+        }
+        first = false;
+        if (load) {
+          int ki = PF(F_KINDID, mys);
+          o = mk3(PFf(F_OX, mys), PFf(F_OY, mys), PFf(F_OZ, mys)); d = mk3(PFf(F_DX, mys), PFf(F_DY, mys), PFf(F_DZ, mys));
+          best.t = PFf(F_T, mys); best.kind = ki & 7; best.id = ki >> 3; best.u = PFf(F_U, mys); best.v = PFf(F_V, mys);
+          cur = PF(F_CUR, mys); sp = PF(F_SP, mys); best_i = PF(F_BESTI, mys);
+          R = blas_ray(o, d);
+          load = false;
+        }
+        mA = __ballot(mys >= 0);
+        nA = __popcll(mA);
+        if (nA < exit_below) break;
+        if (++steps > step_cap) { watchdog = true; break; }
+#ifdef URT_STAMPS
+        ph_trips[3]++; ph_lanes[3] += (unsigned long long)nA;
+#endif
+        // majority vote: this trip runs EITHER the interior-node step OR the leaf step (see mode 3)
+        bool active = mys >= 0;
+        bool interior = active && cur >= 0;
+        int nI = __popcll(__ballot(interior));
+        if (nI >= nA - nI) {
+          if (interior) cur = blas_node_step<COUNT>(S, cur, R, best.t, bl, sp, lc);
+        } else if (active && !interior) {
+          test_leaf<COUNT>(S, cur, o, d, best, best_i, lc);
+          cur = blas_pop(bl, sp);
+        }
+        if (active && cur == kBlasDone) {                              // ray finished: back to the object-level walk (RS:323-325)
+          PFset(F_T, mys, best.t); PF(F_KINDID, mys) = (best.id << 3) | best.kind; PFset(F_U, mys, best.u); PFset(F_V, mys, best.v);
+          stt[mys] = ((PF(F_CHECK, mys) >> 1) == 0 && S.n_spheres == 0) ? PS_SHADE : PS_RESUME;   // nothing of Trace() left: shade next
+          pin[lane] = -1;
+          mys = -1;
+        }
+      }
+      if (mys >= 0) {                                                  // yield: the traversal stays pinned to this lane
+        PFset(F_T, mys, best.t); PF(F_KINDID, mys) = (best.id << 3) | best.kind; PFset(F_U, mys, best.u); PFset(F_V, mys, best.v);
+        PF(F_CUR, mys) = cur; PF(F_SP, mys) = sp; PF(F_BESTI, mys) = best_i;
+        stt[mys] = PS_PINNED;
+        pin[lane] = mys;
+      }
+    } else {
+      // ---------------- SHADE + bookkeeping of CSMain's loops (RS:444-468) ----------------
+      int total;
+      int mine = pool_select<K>(stt, list, PS_SHADE, PS_SHADE, total);
+      if (mine >= 0) {
+        int pix = PF(F_PIX, mine), k = PF(F_K, mine), ray_i = PF(F_RAYI, mine), ki = PF(F_KINDID, mine);
+        int x = pix & 0xffff, y = (int)((unsigned)pix >> 16);
+        float px = (float)x, py = (float)y, seed = PFf(F_SEED, mine);
+        v3 o = mk3(PFf(F_OX, mine), PFf(F_OY, mine), PFf(F_OZ, mine)), d = mk3(PFf(F_DX, mine), PFf(F_DY, mine), PFf(F_DZ, mine));
+        v3 energy = mk3(PFf(F_EX, mine), PFf(F_EY, mine), PFf(F_EZ, mine)), res = mk3(PFf(F_RX, mine), PFf(F_RY, mine), PFf(F_RZ, mine));
+        HitRec best; best.t = PFf(F_T, mine); best.kind = ki & 7; best.id = ki >> 3; best.u = PFf(F_U, mine); best.v = PFf(F_V, mine);
+        bool cont = shade<COUNT>(S, best, o, d, energy, res, seed, px, py, lc);
+        k++;
+        int nst = PS_FRONT;
+        if (!cont || k >= P.num_bounces) {
+          v3 avg = multi ? mk3(PFf(F_AX, mine), PFf(F_AY, mine), PFf(F_AZ, mine)) : mk3(0, 0, 0);
+          avg = avg + res;
+          ray_i++;
+          if (ray_i < P.num_rays) {
+            res = mk3(0, 0, 0); energy = mk3(1, 1, 1); k = 0;
+            camera_ray<kPOffAfterScene>(P, x, y, seed, o, d);
+            if (multi) { PFset(F_AX, mine, avg.x); PFset(F_AY, mine, avg.y); PFset(F_AZ, mine, avg.z); }
+          } else {
+            float n = (float)P.num_rays;
+            result[(size_t)y * P.width + x] = make_float4(avg.x / n, avg.y / n, avg.z / n, 1.0f);
+            nst = PS_FREE;
+          }
+        }
+        if (nst != PS_FREE) {
+          PF(F_K, mine) = k; PF(F_RAYI, mine) = ray_i; PFset(F_SEED, mine, seed);
+          PFset(F_OX, mine, o.x); PFset(F_OY, mine, o.y); PFset(F_OZ, mine, o.z);
+          PFset(F_DX, mine, d.x); PFset(F_DY, mine, d.y); PFset(F_DZ, mine, d.z);
+          PFset(F_EX, mine, energy.x); PFset(F_EY, mine, energy.y); PFset(F_EZ, mine, energy.z);
+          PFset(F_RX, mine, res.x); PFset(F_RY, mine, res.y); PFset(F_RZ, mine, res.z);
+        }
+        stt[mine] = nst;
+      }
+    }
+#ifdef URT_STAMPS
+    ph_t[ph_id] += wall_clock64() - t_ph;
+#endif
+  }
+#ifdef URT_STAMPS
+  if ((threadIdx.x & 63) == 0) {
+    unsigned long long* sp_ = (unsigned long long*)(next + kWorkShards * 32);
+    size_t w = (size_t)blockIdx.x * 32;
+    for (int q = 0; q < 4; q++) { sp_[w + q] = ph_t[q]; sp_[w + 4 + q] = ph_lanes[q]; sp_[w + 8 + q] = ph_trips[q]; }
+    sp_[w + 12] = t_begin; sp_[w + 13] = wall_clock64(); sp_[w + 14] = t_dry; sp_[w + 15] = 0;
+    sp_[w + 16] = ph_trips[4]; sp_[w + 17] = ph_lanes[4]; sp_[w + 18] = wave_iters;
+  }
+#endif
+#undef PF
+#undef PFf
+#undef PFset
+  if (watchdog && (threadIdx.x & 63) == 0) atomicAdd(&ctr[blockIdx.x & (kCounterShards - 1)].watchdog, 1ull);
   flush_counters<COUNT>(lc, ctr);
 }
 
@@ -991,6 +1325,40 @@ hipError_t launch_sched(const DevScene& S, const FrameParams& P, float4* result,
   if (count) hipLaunchKernelGGL(k_sched<true>, dim3(n_blocks), dim3(P.block_threads), lds, st, S, P, result, ctr, next);
   else hipLaunchKernelGGL(k_sched<false>, dim3(n_blocks), dim3(P.block_threads), lds, st, S, P, result, ctr, next);
   return hipGetLastError();
+}
+
+size_t pool_lds_bytes(const FrameParams& P, int k) {
+  size_t np = (size_t)64 * (size_t)k;
+  size_t fields = P.num_rays > 1 ? F_COUNTN : F_COUNT1;
+  return ((size_t)P.blas_stack * 64 + 64 + np + np + fields * np + (size_t)P.tlas_stack * np) * sizeof(int);
+}
+
+template <int K>
+static hipError_t launch_pool_k(const DevScene& S, const FrameParams& P, float4* result, DevCounters* ctr, unsigned int* next,
+                                int n_blocks, bool count, hipStream_t st) {
+  size_t lds = pool_lds_bytes(P, K);
+  if (lds > 64 * 1024) {            // above the default dynamic-LDS limit the kernel attribute has to be raised
+    hipError_t e = count ? hipFuncSetAttribute((const void*)k_pool<true, K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                         : hipFuncSetAttribute((const void*)k_pool<false, K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  if (count) hipLaunchKernelGGL((k_pool<true, K>), dim3(n_blocks), dim3(64), lds, st, S, P, result, ctr, next);
+  else hipLaunchKernelGGL((k_pool<false, K>), dim3(n_blocks), dim3(64), lds, st, S, P, result, ctr, next);
+  return hipGetLastError();
+}
+
+hipError_t launch_pool(const DevScene& S, const FrameParams& P, float4* result, DevCounters* ctr, unsigned int* next,
+                       int n_blocks, int k, bool count, hipStream_t st) {
+  if (n_blocks <= 0) return hipSuccess;
+  if (P.width > 65535 || P.height > 65535 || k < 1 || k > 4) return hipErrorInvalidValue;   // pixel packed as y << 16 | x
+  hipError_t e = hipMemsetAsync(next, 0, kWorkShards * 32 * sizeof(unsigned int), st);
+  if (e != hipSuccess) return e;
+  switch (k) {
+    case 1: return launch_pool_k<1>(S, P, result, ctr, next, n_blocks, count, st);
+    case 2: return launch_pool_k<2>(S, P, result, ctr, next, n_blocks, count, st);
+    case 3: return launch_pool_k<3>(S, P, result, ctr, next, n_blocks, count, st);
+    default: return launch_pool_k<4>(S, P, result, ctr, next, n_blocks, count, st);
+  }
 }
 
 hipError_t launch_blit_add(const float4* src, float4* dst, size_t n_pixels, float sample, hipStream_t st) {
