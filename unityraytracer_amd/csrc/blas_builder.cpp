@@ -179,6 +179,32 @@ bool build_blas(const uint8_t* mesh_objects, int n_meshes, const float* vertices
     out.mesh_root[(size_t)m] = B.build(0, (int)B.prims.size(), 1, root);
     out.max_depth = std::max(out.max_depth, B.max_depth);
   }
+  // Renumber the interior nodes so that the first kTopOrderNodes indices are the TOP of the forest in breadth-first order
+  // (all roots, then their children, ...): the phase-scheduled kernel keeps nodes [0, T) in LDS and walks them before a ray
+  // joins the wave-wide traversal loop (kernels.hip trace_front).  Deeper nodes keep their depth-first order (subtree
+  // locality).  Only indices change: every ray visits the same nodes in the same order as before.
+  {
+    size_t nn = out.nodes.size() / kBlasNodeFloats;
+    std::vector<int32_t> new_of(nn, -1);
+    std::vector<int32_t> queue;
+    for (int m = 0; m < n_meshes; m++) { int32_t r = out.mesh_root[(size_t)m]; if (r >= 0 && r != kEmptyMeshRoot) queue.push_back(r); }
+    size_t head = 0; int32_t next_id = 0;
+    while (head < queue.size() && next_id < kTopOrderNodes) {
+      int32_t o = queue[head++];
+      new_of[(size_t)o] = next_id++;
+      const float* nd = out.nodes.data() + (size_t)o * kBlasNodeFloats;
+      for (int c = 0; c < 2; c++) { int32_t ch = (int32_t)urt::f_bits(nd[12 + c]); if (ch >= 0) queue.push_back(ch); }
+    }
+    for (size_t o = 0; o < nn; o++) if (new_of[o] < 0) new_of[o] = next_id++;
+    std::vector<float> moved(out.nodes.size());
+    for (size_t o = 0; o < nn; o++) {
+      float* dst = moved.data() + (size_t)new_of[o] * kBlasNodeFloats;
+      std::memcpy(dst, out.nodes.data() + o * kBlasNodeFloats, sizeof(float) * kBlasNodeFloats);
+      for (int c = 0; c < 2; c++) { int32_t ch = (int32_t)urt::f_bits(dst[12 + c]); if (ch >= 0) dst[12 + c] = urt::bits_f((uint32_t)new_of[(size_t)ch]); }
+    }
+    out.nodes.swap(moved);
+    for (int m = 0; m < n_meshes; m++) { int32_t& r = out.mesh_root[(size_t)m]; if (r >= 0 && r != kEmptyMeshRoot) r = new_of[(size_t)r]; }
+  }
   // leaf-ordered triangle and normal records
   size_t nt = out.tri_slot.size();
   out.tri_verts.assign(nt * 12, 0.0f);

@@ -10,6 +10,7 @@ namespace urtd {
 
 static constexpr int kBlasNodeFloats = 16;
 static constexpr int32_t kEmptyMeshRoot = 0x7fffffff;
+static constexpr int32_t kTopOrderNodes = 256;   // node indices [0, this) are the top of the forest in breadth-first order
 
 struct BlasResult {
   std::vector<float> nodes;            // 16 floats per node (urt_device.h)

@@ -71,6 +71,7 @@ struct urt_context {
   DevScene ds{};
   std::vector<void*> scene_allocs;
   int tlas_stack = 2, blas_stack = 2;
+  int n_blas_nodes = 0;                     // interior nodes of the triangle-BVH forest (all meshes)
   unsigned int watchdog_steps = 1u << 16;
   float4* zero_sky = nullptr;
 
@@ -90,6 +91,9 @@ struct urt_context {
   int opt_count_stats = 0, opt_time_dispatch = 0, opt_kernel_mode = 3;
   int opt_block_threads = 64, opt_xcd_run = 1, opt_refill_min = 32, opt_waves_per_cu = 0 /* auto */, opt_blas_min = 28, opt_blas_exit = 6;
   int opt_pool_k = 2, opt_pool_refill = 32, opt_pool_blas_min = 48, opt_pool_blas_exit = 8, opt_pool_inloop = 16, opt_pool_other_min = 24;   // kernel_mode 4
+  int opt_sched_block = 0;                  // kernel_mode 3: threads per workgroup (64 or 256; 0 = 256 when there is a BVH top to share)
+  int opt_top_front = -1;                   // kernel_mode 3: top-of-forest walk inside the object-level phase (-1 = when the scene has several meshes)
+  int opt_top_nodes = 64;                   // kernel_mode 3: triangle-BVH nodes kept in LDS (0 = none)
 };
 
 namespace {
@@ -232,6 +236,7 @@ int prepare_scene(urt_context* ctx) {
     return fail(ctx, URT_ERR_SCENE, "object-level BVH deeper than the reference's 32-entry traversal stack (RS:73-74)");
   ctx->tlas_stack = std::max(2, lv + 1);
   ctx->blas_stack = std::max(2, blas.max_depth + 1);
+  ctx->n_blas_nodes = (int)std::min<size_t>(0x7fffffff, blas.nodes.size() / kBlasNodeFloats);
   // a ray with NaN components passes every slab test and walks the whole tree once: (nodes + leaves) trips per lane, and the
   // majority vote can make a lane wait a trip for every trip it runs; 8x that is a bound no correct traversal reaches
   ctx->watchdog_steps = (unsigned int)std::min<size_t>(0x7fffffffu, 8 * (blas.nodes.size() / kBlasNodeFloats + blas.tri_slot.size()) + 4096);
@@ -346,7 +351,15 @@ int do_dispatch(urt_context* ctx, int kernel, int gx, int gy, int gz, int first_
   hipError_t le;
   if (mode == 1) le = launch_wavefront(S, P, ctx->q, res->dev, ctx->d_counters, count, ctx->stream);
   else if (mode == 2 || mode == 3) {
-    if (mode == 3) P.block_threads = 64;                       // one wave per workgroup: independent scheduling, 5 waves/SIMD
+    if (mode == 3) {
+      // independent waves; the waves of a workgroup share one LDS copy of the top of the triangle-BVH forest, which shrinks
+      // until 5 waves/SIMD (what 96 VGPRs allow) fit the 160 KiB of a CU next to their traversal stacks
+      int t = std::min(std::min(ctx->opt_top_nodes, (int)kTopOrderNodes), ctx->n_blas_nodes);
+      P.block_threads = ctx->opt_sched_block > 0 ? ctx->opt_sched_block : (t > 0 ? 256 : 64);   // nothing to share: single waves
+      P.top_nodes = t;
+      size_t groups = 20 / (size_t)(P.block_threads / 64);
+      while (P.top_nodes > 0 && sched_lds_bytes(P) * groups > 156 * 1024) P.top_nodes /= 2;   // (a little of the 160 KiB goes to allocation granules)
+    }
     int waves_per_block = P.block_threads / 64;
     long want = ((long)P.tiles_x * P.n_strips + waves_per_block - 1) / waves_per_block;
     // resident waves per CU: every slot the registers allow (k_sched: 96 VGPRs -> 5 waves/SIMD = 20 per CU).  While the
@@ -357,7 +370,7 @@ int do_dispatch(urt_context* ctx, int kernel, int gx, int gy, int gz, int first_
     long resident = (long)ctx->n_cus * wpc / waves_per_block;
     int nb = (int)std::max(1L, std::min(want, resident));
     le = mode == 2 ? launch_persist(S, P, res->dev, ctx->d_counters, ctx->d_next, nb, count, ctx->stream)
-                   : launch_sched(S, P, res->dev, ctx->d_counters, ctx->d_next, nb, count, ctx->stream);
+                   : launch_sched(S, P, res->dev, ctx->d_counters, ctx->d_next, nb, ctx->opt_top_front < 0 ? S.n_meshes > 1 : ctx->opt_top_front != 0, count, ctx->stream);
   } else if (mode == 4) {
     // one wave per workgroup; residency is bounded by the LDS one wave's path pool takes (kernels.hip k_pool)
     P.block_threads = 64;
@@ -729,6 +742,15 @@ int urt_set_option(urt_context* ctx, const char* name, int value) {
   } else if (std::strcmp(name, "waves_per_cu") == 0) {
     if (value < 0 || value > 32) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "waves_per_cu must be in [0, 32] (0 = auto)");
     ctx->opt_waves_per_cu = value;
+  } else if (std::strcmp(name, "sched_block") == 0) {
+    if (value != 0 && value != 64 && value != 256) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "sched_block must be 0 (auto), 64 or 256");
+    ctx->opt_sched_block = value;
+  } else if (std::strcmp(name, "top_front") == 0) {
+    if (value < -1 || value > 1) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "top_front must be -1 (auto), 0 or 1");
+    ctx->opt_top_front = value;
+  } else if (std::strcmp(name, "top_nodes") == 0) {
+    if (value < 0 || value > kTopOrderNodes) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "top_nodes must be in [0, 256]");
+    ctx->opt_top_nodes = value;
   } else if (std::strcmp(name, "pool_k") == 0) {
     if (value < 1 || value > 4) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "pool_k must be in [1, 4]");
     ctx->opt_pool_k = value;

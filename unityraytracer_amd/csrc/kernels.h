@@ -14,8 +14,10 @@ hipError_t launch_wavefront(const DevScene& S, const FrameParams& P, const PathQ
 hipError_t launch_persist(const DevScene& S, const FrameParams& P, float4* result, DevCounters* ctr, unsigned int* next,
                           int n_blocks, bool count, hipStream_t st);
 // mode 3: persistent waves whose lanes are scheduled by phase (FRONT / BLAS / SHADE) inside the wave
+// top_in_front: walk the LDS-resident top of the BVH forest inside the object-level phase (pays in multi-mesh scenes)
 hipError_t launch_sched(const DevScene& S, const FrameParams& P, float4* result, DevCounters* ctr, unsigned int* next,
-                        int n_blocks, bool count, hipStream_t st);
+                        int n_blocks, bool top_in_front, bool count, hipStream_t st);
+size_t sched_lds_bytes(const FrameParams& P);          // dynamic LDS of one workgroup (4 waves) of mode 3
 // mode 4: persistent waves over a pool of 64*k paths per wave kept in LDS, phases run on compacted lanes
 hipError_t launch_pool(const DevScene& S, const FrameParams& P, float4* result, DevCounters* ctr, unsigned int* next,
                        int n_blocks, int k, bool count, hipStream_t st);

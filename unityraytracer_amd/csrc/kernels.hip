@@ -143,16 +143,7 @@ __device__ __forceinline__ int32_t blas_pop(int* stk, int& sp) {
 
 // One interior-node step: slab-test both children against [0, tbest], descend into the nearer hit child (ties: child 0),
 // push the other; returns the next cursor.
-template <bool COUNT>
-__device__ __forceinline__ int32_t blas_node_step(const DevScene& S, int32_t cur, const BlasRay& R, float tbest, int* stk, int& sp,
-                                                  LocalCounters& lc, unsigned long long* dbg_loaded = nullptr) {
-  if (COUNT) lc.blas_nodes++;
-  const float4* n = S.blas_nodes + 4 * (size_t)cur;
-  float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
-  if (dbg_loaded) {                      // diagnostic builds: when did the node arrive?
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(q0.x), "+v"(q1.x), "+v"(q2.x), "+v"(q3.x) : : "memory");
-    *dbg_loaded = __builtin_amdgcn_s_memtime();
-  }
+__device__ __forceinline__ int32_t blas_node_eval(float4 q0, float4 q1, float4 q2, float4 q3, const BlasRay& R, float tbest, int* stk, int& sp) {
   // child 0: min (q0.x q0.y q0.z) max (q0.w q1.x q1.y)
   float a1x = f_fma(q0.x, R.idir.x, R.nop.x), a2x = f_fma(q0.w, R.idir.x, R.nom.x);
   float a1y = f_fma(q0.y, R.idir.y, R.nop.y), a2y = f_fma(q1.x, R.idir.y, R.nom.y);
@@ -176,6 +167,30 @@ __device__ __forceinline__ int32_t blas_node_step(const DevScene& S, int32_t cur
   if (h0) return c0;
   if (h1) return c1;
   return blas_pop(stk, sp);
+}
+
+// One interior-node step: slab-test both children against [0, tbest], descend into the nearer hit child (ties: child 0),
+// push the other; returns the next cursor.
+template <bool COUNT>
+__device__ __forceinline__ int32_t blas_node_step(const DevScene& S, int32_t cur, const BlasRay& R, float tbest, int* stk, int& sp,
+                                                  LocalCounters& lc, unsigned long long* dbg_loaded = nullptr) {
+  if (COUNT) lc.blas_nodes++;
+  const float4* n = S.blas_nodes + 4 * (size_t)cur;
+  float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
+  if (dbg_loaded) {                      // diagnostic builds: when did the node arrive?
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(q0.x), "+v"(q1.x), "+v"(q2.x), "+v"(q3.x) : : "memory");
+    *dbg_loaded = __builtin_amdgcn_s_memtime();
+  }
+  return blas_node_eval(q0, q1, q2, q3, R, tbest, stk, sp);
+}
+
+// The same step on a node of the LDS-resident top of the forest (nodes [0, top_nodes), 4 x float4 each)
+template <bool COUNT>
+__device__ __forceinline__ int32_t blas_node_step_top(const float4* top, int32_t cur, const BlasRay& R, float tbest, int* stk, int& sp,
+                                                      LocalCounters& lc) {
+  if (COUNT) lc.blas_nodes++;
+  const float4* n = top + 4 * cur;
+  return blas_node_eval(n[0], n[1], n[2], n[3], R, tbest, stk, sp);
 }
 
 template <bool COUNT>
@@ -628,9 +643,13 @@ __global__ __launch_bounds__(256) void k_persist(DevScene S, FrameParams P, floa
 // (returns true, `cur` = its root) or to the end of Trace (returns false; `best` is final).  `check`/`seen` are the
 // object-level walk's stack height and its never-reset `tests` flag (RS:296-297, A.5); the object-level stack entry e of
 // this path is tl[e * stride].
-template <bool COUNT>
+// TOPF (multi-mesh scenes): a ray entering a MeshObject walks the LDS-resident top of the forest (`top`, nodes
+// [0, top_nodes)) right here, far children going on its traversal stack `bl` (height *sp_out): when nothing of the mesh is
+// near the ray the heap walk simply continues — no round trip through the traversal phase for a mesh that is only grazed.
+template <bool COUNT, bool TOPF = false>
 __device__ __forceinline__ bool trace_front(const DevScene& S, bool fresh, v3 o, v3 d, HitRec& best, int& check, bool& seen,
-                                            int* tl, int stride, int32_t& cur, LocalCounters& lc) {
+                                            int* tl, int stride, int32_t& cur, LocalCounters& lc,
+                                            const float4* top = nullptr, int top_nodes = 0, int* bl = nullptr, int* sp_out = nullptr) {
   if (fresh) {
     lc.rays++;
     best.t = URT_INF; best.kind = 0; best.id = 0; best.u = 0; best.v = 0;
@@ -659,7 +678,19 @@ __device__ __forceinline__ bool trace_front(const DevScene& S, bool fresh, v3 o,
       if (root < 0 && root != kBlasDone) {               // a mesh of <= 8 triangles is one leaf: test it here, no phase switch
         int bi_local = -1;
         test_leaf<COUNT>(S, root, o, d, best, bi_local, lc);
-      } else if (root != kEmptyMeshRoot) { cur = root; return true; }
+      } else if (root != kEmptyMeshRoot) {
+        if (TOPF) {
+          int sp = 0;
+          if (root < top_nodes) {
+            BlasRay R = blas_ray(o, d);
+            do root = blas_node_step_top<COUNT>(top, root, R, best.t, bl, sp, lc); while (root >= 0 && root < top_nodes);
+          }
+          *sp_out = sp;
+          if (root == kBlasDone) continue;                   // nothing of this mesh is near the ray: on with the heap walk
+        }
+        cur = root;
+        return true;
+      }
     }
   }
   if (S.n_spheres > 0) {                                   // IntersectSphereBVH RS:329-361
@@ -704,14 +735,20 @@ static constexpr unsigned int kWatchdogIters = 1u << 24;    // scheduler trips p
 #ifndef URT_SCHED_OCC
 #define URT_SCHED_OCC 5
 #endif
-template <bool COUNT>
-__global__ __launch_bounds__(64, URT_SCHED_OCC) void k_sched(DevScene S, FrameParams P, float4* __restrict__ result, DevCounters* ctr,
+template <bool COUNT, int BLOCK, bool TOPF>
+__global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, FrameParams P, float4* __restrict__ result, DevCounters* ctr,
                                                unsigned int* __restrict__ next) {
-  int *tl, *bl;
-  lane_stacks(P, tl, bl);
+  // LDS of the workgroup: [top of the triangle-BVH forest: top_nodes x 64 B, shared by its waves][stacks of wave 0][wave 1]...
+  // The waves of a workgroup share nothing else and never synchronise after this copy.
+  extern __shared__ int lds[];
+  const float4* top = (const float4*)lds;
+  for (int i = threadIdx.x; i < P.top_nodes * 4; i += blockDim.x) ((float4*)lds)[i] = S.blas_nodes[i];
+  __syncthreads();
+  int* tl = lds + P.top_nodes * 16 + (threadIdx.x >> 6) * ((P.tlas_stack + P.blas_stack) * 64) + (threadIdx.x & 63);
+  int* bl = tl + P.tlas_stack * 64;
   LocalCounters lc;
   const unsigned int ntiles = (unsigned int)(P.tiles_x * P.n_strips);
-  WorkCursor wc; wc.shard = blockIdx.x & (kWorkShards - 1u);
+  WorkCursor wc; wc.shard = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (kWorkShards - 1u);
   bool exhausted = false;
   int st = ST_DEAD;
   // path state
@@ -772,13 +809,22 @@ __global__ __launch_bounds__(64, URT_SCHED_OCC) void k_sched(DevScene S, FramePa
     if (phase == ST_FRONT) {
       // ---------------- FRONT / RESUME: Trace() up to the next triangle-BVH visit (RS:364-383) ----------------
       if (st == ST_FRONT || st == ST_RESUME) {
-        if (trace_front<COUNT>(S, st == ST_FRONT, o, d, best, check, seen, tl, 64, cur, lc)) { sp = 0; best_i = -1; st = ST_BLAS; }
+        sp = 0;
+        bool need = TOPF ? trace_front<COUNT, true>(S, st == ST_FRONT, o, d, best, check, seen, tl, 64, cur, lc, top, P.top_nodes, bl, &sp)
+                         : trace_front<COUNT>(S, st == ST_FRONT, o, d, best, check, seen, tl, 64, cur, lc);
+        if (need) { best_i = -1; st = ST_BLAS; }
         else st = ST_SHADE;
       }
     } else if (phase == ST_BLAS) {
       // ---------------- BLAS: triangle BVH of one MeshObject, resumable ----------------
       bool mine = st == ST_BLAS;
       BlasRay R = blas_ray(o, d);
+      // A ray that has just entered a MeshObject first walks the LDS-resident top of the forest (nodes [0, top_nodes)) on its
+      // own, at LDS latency: the first ~6 of its ~12 node visits then never wait for another lane's cache miss.  Same
+      // visits in the same order as the wave-wide loop below would make; far children go on the lane's stack as usual.
+      if (mine && cur >= 0 && cur < P.top_nodes) {
+        do cur = blas_node_step_top<COUNT>(top, cur, R, best.t, bl, sp, lc); while (cur >= 0 && cur < P.top_nodes);
+      }
       bool active = mine && cur != kBlasDone;
       unsigned int steps = 0;
       for (;;) {
@@ -1315,16 +1361,40 @@ hipError_t launch_persist(const DevScene& S, const FrameParams& P, float4* resul
   return hipGetLastError();
 }
 
+size_t sched_lds_bytes(const FrameParams& P) {
+  return (size_t)P.top_nodes * 64 + (size_t)(P.tlas_stack + P.blas_stack) * 64 * (size_t)(P.block_threads / 64) * sizeof(int);
+}
+
+template <bool COUNT, int BLOCK, bool TOPF>
+static hipError_t launch_sched_t(const DevScene& S, const FrameParams& P, float4* result, DevCounters* ctr, unsigned int* next,
+                                 int n_blocks, size_t lds, hipStream_t st) {
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_sched<COUNT, BLOCK, TOPF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL((k_sched<COUNT, BLOCK, TOPF>), dim3(n_blocks), dim3(BLOCK), lds, st, S, P, result, ctr, next);
+  return hipGetLastError();
+}
+
+template <bool COUNT, int BLOCK>
+static hipError_t launch_sched_b(const DevScene& S, const FrameParams& P, float4* result, DevCounters* ctr, unsigned int* next,
+                                 int n_blocks, size_t lds, bool top_in_front, hipStream_t st) {
+  return top_in_front ? launch_sched_t<COUNT, BLOCK, true>(S, P, result, ctr, next, n_blocks, lds, st)
+                      : launch_sched_t<COUNT, BLOCK, false>(S, P, result, ctr, next, n_blocks, lds, st);
+}
+
 hipError_t launch_sched(const DevScene& S, const FrameParams& P, float4* result, DevCounters* ctr, unsigned int* next,
-                        int n_blocks, bool count, hipStream_t st) {
+                        int n_blocks, bool top_in_front, bool count, hipStream_t st) {
   if (n_blocks <= 0) return hipSuccess;
-  if (P.block_threads != 64) return hipErrorInvalidValue;     // k_sched is built for one wave per workgroup (launch bounds 64, 5 waves/SIMD)
+  if (P.block_threads != 64 && P.block_threads != 256) return hipErrorInvalidValue;   // independent waves; a workgroup shares the LDS top-of-tree copy
   hipError_t e = hipMemsetAsync(next, 0, kWorkShards * 32 * sizeof(unsigned int), st);
   if (e != hipSuccess) return e;
-  size_t lds = stack_lds_bytes(P);
-  if (count) hipLaunchKernelGGL(k_sched<true>, dim3(n_blocks), dim3(P.block_threads), lds, st, S, P, result, ctr, next);
-  else hipLaunchKernelGGL(k_sched<false>, dim3(n_blocks), dim3(P.block_threads), lds, st, S, P, result, ctr, next);
-  return hipGetLastError();
+  size_t lds = sched_lds_bytes(P);
+  if (P.top_nodes <= 0) top_in_front = false;
+  if (P.block_threads == 64) return count ? launch_sched_b<true, 64>(S, P, result, ctr, next, n_blocks, lds, top_in_front, st)
+                                          : launch_sched_b<false, 64>(S, P, result, ctr, next, n_blocks, lds, top_in_front, st);
+  return count ? launch_sched_b<true, 256>(S, P, result, ctr, next, n_blocks, lds, top_in_front, st)
+               : launch_sched_b<false, 256>(S, P, result, ctr, next, n_blocks, lds, top_in_front, st);
 }
 
 size_t pool_lds_bytes(const FrameParams& P, int k) {
