@@ -92,6 +92,7 @@ struct urt_context {
   int opt_block_threads = 64, opt_xcd_run = 1, opt_refill_min = 32, opt_waves_per_cu = 0 /* auto */, opt_blas_min = 28, opt_blas_exit = 6;
   int opt_pool_k = 2, opt_pool_refill = 32, opt_pool_blas_min = 48, opt_pool_blas_exit = 8, opt_pool_inloop = 16, opt_pool_other_min = 24;   // kernel_mode 4
   int opt_sched_block = 0;                  // kernel_mode 3: threads per workgroup (64 or 256; 0 = 256 when there is a BVH top to share)
+  int opt_lds_tlas = 1;                     // kernel_mode 3: object-level heaps, roots and spheres in LDS when small
   int opt_top_front = -1;                   // kernel_mode 3: top-of-forest walk inside the object-level phase (-1 = when the scene has several meshes)
   int opt_top_nodes = 64;                   // kernel_mode 3: triangle-BVH nodes kept in LDS (0 = none)
 };
@@ -355,10 +356,16 @@ int do_dispatch(urt_context* ctx, int kernel, int gx, int gy, int gz, int first_
       // independent waves; the waves of a workgroup share one LDS copy of the top of the triangle-BVH forest, which shrinks
       // until 5 waves/SIMD (what 96 VGPRs allow) fit the 160 KiB of a CU next to their traversal stacks
       int t = std::min(std::min(ctx->opt_top_nodes, (int)kTopOrderNodes), ctx->n_blas_nodes);
-      P.block_threads = ctx->opt_sched_block > 0 ? ctx->opt_sched_block : (t > 0 ? 256 : 64);   // nothing to share: single waves
+      // small object-level tables (<= 256 entries) also live in LDS: their walk is a chain of dependent fetches
+      P.lds_mesh = ctx->opt_lds_tlas && S.n_mesh_tlas > 0 && S.n_mesh_tlas <= 256 && S.n_meshes <= 256;
+      P.lds_sphere = ctx->opt_lds_tlas && S.n_sphere_tlas > 0 && S.n_sphere_tlas <= 256 && S.n_spheres <= 256;
+      bool shared = t > 0 || P.lds_mesh || P.lds_sphere;
+      P.block_threads = ctx->opt_sched_block > 0 ? ctx->opt_sched_block : (shared ? 256 : 64);   // nothing to share: single waves
       P.top_nodes = t;
       size_t groups = 20 / (size_t)(P.block_threads / 64);
-      while (P.top_nodes > 0 && sched_lds_bytes(P) * groups > 156 * 1024) P.top_nodes /= 2;   // (a little of the 160 KiB goes to allocation granules)
+      const size_t budget = 156 * 1024;                          // (a little of the 160 KiB goes to allocation granules)
+      while (P.top_nodes > 0 && sched_lds_bytes(S, P) * groups > budget) P.top_nodes /= 2;
+      if (sched_lds_bytes(S, P) * groups > budget) { P.lds_mesh = 0; P.lds_sphere = 0; }
     }
     int waves_per_block = P.block_threads / 64;
     long want = ((long)P.tiles_x * P.n_strips + waves_per_block - 1) / waves_per_block;
@@ -745,6 +752,8 @@ int urt_set_option(urt_context* ctx, const char* name, int value) {
   } else if (std::strcmp(name, "sched_block") == 0) {
     if (value != 0 && value != 64 && value != 256) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "sched_block must be 0 (auto), 64 or 256");
     ctx->opt_sched_block = value;
+  } else if (std::strcmp(name, "lds_tlas") == 0) {
+    ctx->opt_lds_tlas = value ? 1 : 0;
   } else if (std::strcmp(name, "top_front") == 0) {
     if (value < -1 || value > 1) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "top_front must be -1 (auto), 0 or 1");
     ctx->opt_top_front = value;

@@ -17,7 +17,7 @@ hipError_t launch_persist(const DevScene& S, const FrameParams& P, float4* resul
 // top_in_front: walk the LDS-resident top of the BVH forest inside the object-level phase (pays in multi-mesh scenes)
 hipError_t launch_sched(const DevScene& S, const FrameParams& P, float4* result, DevCounters* ctr, unsigned int* next,
                         int n_blocks, bool top_in_front, bool count, hipStream_t st);
-size_t sched_lds_bytes(const FrameParams& P);          // dynamic LDS of one workgroup (4 waves) of mode 3
+size_t sched_lds_bytes(const DevScene& S, const FrameParams& P);          // dynamic LDS of one workgroup (4 waves) of mode 3
 // mode 4: persistent waves over a pool of 64*k paths per wave kept in LDS, phases run on compacted lanes
 hipError_t launch_pool(const DevScene& S, const FrameParams& P, float4* result, DevCounters* ctr, unsigned int* next,
                        int n_blocks, int k, bool count, hipStream_t st);

@@ -62,9 +62,11 @@ __device__ __forceinline__ bool tlas_slab(float4 a, float4 b, v3 o, v3 rcp) {
 
 // RS:175-196 without the material copy (fetched at shading time)
 template <bool COUNT>
-__device__ __forceinline__ void intersect_sphere(const DevScene& S, int idx, v3 o, v3 d, HitRec& best, LocalCounters& lc) {
+__device__ __forceinline__ void intersect_sphere(const DevScene& S, int idx, v3 o, v3 d, HitRec& best, LocalCounters& lc,
+                                                 const float4* lds_pr = nullptr) {
   if (COUNT) lc.sphere_tests++;
-  float4 pr = S.sphere_pr[idx];
+  float4 pr;
+  if (lds_pr) pr = lds_pr[idx]; else pr = S.sphere_pr[idx];
   v3 dd = o - xyz(pr);
   float p1 = -dot(d, dd);
   float p2sqr = p1 * p1 - dot(dd, dd) + pr.w * pr.w;
@@ -646,9 +648,18 @@ __global__ __launch_bounds__(256) void k_persist(DevScene S, FrameParams P, floa
 // TOPF (multi-mesh scenes): a ray entering a MeshObject walks the LDS-resident top of the forest (`top`, nodes
 // [0, top_nodes)) right here, far children going on its traversal stack `bl` (height *sp_out): when nothing of the mesh is
 // near the ray the heap walk simply continues — no round trip through the traversal phase for a mesh that is only grazed.
+// FrontLds: LDS copies of the small object-level tables (null = read the global buffer).  An object-level walk is a chain
+// of dependent fetches (C2: 19 heap nodes per ray); from LDS each costs tens of cycles instead of an L1/L2 round trip.
+struct FrontLds {
+  const float4* mesh_tlas = nullptr;     // [2 * n_mesh_tlas]
+  const int32_t* mesh_root = nullptr;    // [n_meshes]
+  const float4* sphere_tlas = nullptr;   // [2 * n_sphere_tlas]
+  const float4* sphere_pr = nullptr;     // [n_spheres]
+};
+
 template <bool COUNT, bool TOPF = false>
 __device__ __forceinline__ bool trace_front(const DevScene& S, bool fresh, v3 o, v3 d, HitRec& best, int& check, bool& seen,
-                                            int* tl, int stride, int32_t& cur, LocalCounters& lc,
+                                            int* tl, int stride, int32_t& cur, LocalCounters& lc, const FrontLds& L = FrontLds(),
                                             const float4* top = nullptr, int top_nodes = 0, int* bl = nullptr, int* sp_out = nullptr) {
   if (fresh) {
     lc.rays++;
@@ -665,7 +676,8 @@ __device__ __forceinline__ bool trace_front(const DevScene& S, bool fresh, v3 o,
     bool hit = false; int index = -1;
     if (bi < S.n_mesh_tlas) {
       if (COUNT) lc.tlas_nodes++;
-      float4 a = S.mesh_tlas[2 * bi], b = S.mesh_tlas[2 * bi + 1];
+      float4 a, b;
+      if (L.mesh_tlas) { a = L.mesh_tlas[2 * bi]; b = L.mesh_tlas[2 * bi + 1]; } else { a = S.mesh_tlas[2 * bi]; b = S.mesh_tlas[2 * bi + 1]; }
       index = as_int(a.w);
       hit = tlas_slab(a, b, o, rcp);
     }
@@ -674,7 +686,8 @@ __device__ __forceinline__ bool trace_front(const DevScene& S, bool fresh, v3 o,
       else seen = true;
     }
     if (seen && index >= 0 && index < S.n_meshes) {
-      int32_t root = S.mesh_root[index];
+      int32_t root;
+      if (L.mesh_root) root = L.mesh_root[index]; else root = S.mesh_root[index];
       if (root < 0 && root != kBlasDone) {               // a mesh of <= 8 triangles is one leaf: test it here, no phase switch
         int bi_local = -1;
         test_leaf<COUNT>(S, root, o, d, best, bi_local, lc);
@@ -701,7 +714,8 @@ __device__ __forceinline__ bool trace_front(const DevScene& S, bool fresh, v3 o,
       bool hit = false; int index = -1;
       if (bi < S.n_sphere_tlas) {
         if (COUNT) lc.tlas_nodes++;
-        float4 a = S.sphere_tlas[2 * bi], b = S.sphere_tlas[2 * bi + 1];
+        float4 a, b;
+        if (L.sphere_tlas) { a = L.sphere_tlas[2 * bi]; b = L.sphere_tlas[2 * bi + 1]; } else { a = S.sphere_tlas[2 * bi]; b = S.sphere_tlas[2 * bi + 1]; }
         index = as_int(a.w);
         hit = tlas_slab(a, b, o, rcp);
       }
@@ -709,7 +723,7 @@ __device__ __forceinline__ bool trace_front(const DevScene& S, bool fresh, v3 o,
         if (index < 0) { tl[c2 * stride] = bi * 2 + 1; c2++; tl[c2 * stride] = bi * 2 + 2; c2++; }
         else seen2 = true;
       }
-      if (seen2 && index >= 0 && index < S.n_spheres) intersect_sphere<COUNT>(S, index, o, d, best, lc);
+      if (seen2 && index >= 0 && index < S.n_spheres) intersect_sphere<COUNT>(S, index, o, d, best, lc, L.sphere_pr);
     }
   }
   return false;
@@ -741,10 +755,25 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
   // LDS of the workgroup: [top of the triangle-BVH forest: top_nodes x 64 B, shared by its waves][stacks of wave 0][wave 1]...
   // The waves of a workgroup share nothing else and never synchronise after this copy.
   extern __shared__ int lds[];
-  const float4* top = (const float4*)lds;
-  for (int i = threadIdx.x; i < P.top_nodes * 4; i += blockDim.x) ((float4*)lds)[i] = S.blas_nodes[i];
+  float4* lds4 = (float4*)lds;
+  const float4* top = lds4;
+  for (int i = threadIdx.x; i < P.top_nodes * 4; i += blockDim.x) lds4[i] = S.blas_nodes[i];
+  int at = P.top_nodes * 4;                                     // running offset in float4 units
+  FrontLds L;
+  if (P.lds_mesh) {                                             // object-level mesh heap + MeshObject roots
+    for (int i = threadIdx.x; i < 2 * S.n_mesh_tlas; i += blockDim.x) lds4[at + i] = S.mesh_tlas[i];
+    L.mesh_tlas = lds4 + at; at += 2 * S.n_mesh_tlas;
+    for (int i = threadIdx.x; i < S.n_meshes; i += blockDim.x) ((int32_t*)(lds4 + at))[i] = S.mesh_root[i];
+    L.mesh_root = (const int32_t*)(lds4 + at); at += (S.n_meshes + 3) / 4;
+  }
+  if (P.lds_sphere) {                                           // object-level sphere heap + sphere positions/radii
+    for (int i = threadIdx.x; i < 2 * S.n_sphere_tlas; i += blockDim.x) lds4[at + i] = S.sphere_tlas[i];
+    L.sphere_tlas = lds4 + at; at += 2 * S.n_sphere_tlas;
+    for (int i = threadIdx.x; i < S.n_spheres; i += blockDim.x) lds4[at + i] = S.sphere_pr[i];
+    L.sphere_pr = lds4 + at; at += S.n_spheres;
+  }
   __syncthreads();
-  int* tl = lds + P.top_nodes * 16 + (threadIdx.x >> 6) * ((P.tlas_stack + P.blas_stack) * 64) + (threadIdx.x & 63);
+  int* tl = lds + at * 4 + (threadIdx.x >> 6) * ((P.tlas_stack + P.blas_stack) * 64) + (threadIdx.x & 63);
   int* bl = tl + P.tlas_stack * 64;
   LocalCounters lc;
   const unsigned int ntiles = (unsigned int)(P.tiles_x * P.n_strips);
@@ -810,8 +839,8 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
       // ---------------- FRONT / RESUME: Trace() up to the next triangle-BVH visit (RS:364-383) ----------------
       if (st == ST_FRONT || st == ST_RESUME) {
         sp = 0;
-        bool need = TOPF ? trace_front<COUNT, true>(S, st == ST_FRONT, o, d, best, check, seen, tl, 64, cur, lc, top, P.top_nodes, bl, &sp)
-                         : trace_front<COUNT>(S, st == ST_FRONT, o, d, best, check, seen, tl, 64, cur, lc);
+        bool need = TOPF ? trace_front<COUNT, true>(S, st == ST_FRONT, o, d, best, check, seen, tl, 64, cur, lc, L, top, P.top_nodes, bl, &sp)
+                         : trace_front<COUNT>(S, st == ST_FRONT, o, d, best, check, seen, tl, 64, cur, lc, L);
         if (need) { best_i = -1; st = ST_BLAS; }
         else st = ST_SHADE;
       }
@@ -1361,8 +1390,11 @@ hipError_t launch_persist(const DevScene& S, const FrameParams& P, float4* resul
   return hipGetLastError();
 }
 
-size_t sched_lds_bytes(const FrameParams& P) {
-  return (size_t)P.top_nodes * 64 + (size_t)(P.tlas_stack + P.blas_stack) * 64 * (size_t)(P.block_threads / 64) * sizeof(int);
+size_t sched_lds_bytes(const DevScene& S, const FrameParams& P) {
+  size_t f4 = (size_t)P.top_nodes * 4;
+  if (P.lds_mesh) f4 += 2 * (size_t)S.n_mesh_tlas + ((size_t)S.n_meshes + 3) / 4;
+  if (P.lds_sphere) f4 += 2 * (size_t)S.n_sphere_tlas + (size_t)S.n_spheres;
+  return f4 * 16 + (size_t)(P.tlas_stack + P.blas_stack) * 64 * (size_t)(P.block_threads / 64) * sizeof(int);
 }
 
 template <bool COUNT, int BLOCK, bool TOPF>
@@ -1389,7 +1421,7 @@ hipError_t launch_sched(const DevScene& S, const FrameParams& P, float4* result,
   if (P.block_threads != 64 && P.block_threads != 256) return hipErrorInvalidValue;   // independent waves; a workgroup shares the LDS top-of-tree copy
   hipError_t e = hipMemsetAsync(next, 0, kWorkShards * 32 * sizeof(unsigned int), st);
   if (e != hipSuccess) return e;
-  size_t lds = sched_lds_bytes(P);
+  size_t lds = sched_lds_bytes(S, P);
   if (P.top_nodes <= 0) top_in_front = false;
   if (P.block_threads == 64) return count ? launch_sched_b<true, 64>(S, P, result, ctr, next, n_blocks, lds, top_in_front, st)
                                           : launch_sched_b<false, 64>(S, P, result, ctr, next, n_blocks, lds, top_in_front, st);

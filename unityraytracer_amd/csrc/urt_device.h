@@ -56,6 +56,7 @@ struct FrameParams {
   int blas_min;             // mode 3: lanes parked in BLAS before the traversal phase is scheduled (1..64)
   int blas_exit;            // mode 3: the traversal phase yields when fewer lanes than this are still traversing (1..64)
   int top_nodes;            // mode 3: triangle-BVH nodes [0, top_nodes) are copied to LDS (breadth-first top of the forest); 0 = none
+  int lds_mesh, lds_sphere; // mode 3: keep the object-level mesh heap + roots / sphere heap + spheres in LDS (0/1)
   int pool_inloop;          // mode 4: idle lanes that trigger a re-feed of the traversal phase from the waiting rays (1..64)
   int pool_other_min;       // mode 4: lanes of FRONT / SHADE work that make those phases worth a trip while rays queue for the BVH
   unsigned int watchdog_steps;  // cap on traversal trips per scheduled BLAS phase: a few times (nodes + leaves) of the scene
