@@ -6,7 +6,7 @@ ctx = Context(0)
 lib = _lib.load()
 lib.urt_debug_read_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 import itertools
-for (w, h, b), wpc in itertools.product(((1920, 1080, 8), (3840, 2160, 8)), (4, 16)):
+for (w, h, b), wpc in itertools.product(((1920, 1080, 8), (3840, 2160, 8)), (20,)):
     sc = scenes.config3(w, h); sc.num_bounces = b
     ctx.set_option("kernel_mode", 3); ctx.set_option("waves_per_cu", wpc)
     print(f"--- waves/CU {wpc}")
@@ -33,6 +33,4 @@ for (w, h, b), wpc in itertools.product(((1920, 1080, 8), (3840, 2160, 8)), (4, 
     for q in range(3):
         print(f"   {names[q]:5s}: {t[:, q].sum() / life.sum() * 100:5.1f} % of wave time, {trips[:, q].mean():7.1f} trips/wave, {lanes[:, q].sum() / max(1, trips[:, q].sum()):5.1f} lanes/trip, {t[:, q].sum() / max(1, trips[:, q].sum()):7.2f} us/trip")
     print(f"   BLAS inner: {trips[:, 3].mean():8.1f} steps/wave, {lanes[:, 3].sum() / max(1, trips[:, 3].sum()):5.1f} active lanes/step, {t[:, 1].sum() / max(1, trips[:, 3].sum()) * 1000:7.1f} ns/step")
-    dbg = st[:, 16:21].astype(np.float64); cyc_per_us = (st[:, 15].astype(np.float64) / np.maximum(life, 1e-9)).mean()
-    print(f"   memtime ticks/us {cyc_per_us:.0f}; node steps/wave {dbg[:,0].mean():.0f}: load wait {dbg[:,1].sum()/dbg[:,0].sum()/cyc_per_us*1000:.0f} ns + rest {dbg[:,2].sum()/dbg[:,0].sum()/cyc_per_us*1000:.0f} ns; leaf steps/wave {dbg[:,3].mean():.0f}: {dbg[:,4].sum()/max(1,dbg[:,3].sum())/cyc_per_us*1000:.0f} ns each")
     m.OnDisable()

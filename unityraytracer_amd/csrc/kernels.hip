@@ -175,14 +175,10 @@ __device__ __forceinline__ int32_t blas_node_eval(float4 q0, float4 q1, float4 q
 // push the other; returns the next cursor.
 template <bool COUNT>
 __device__ __forceinline__ int32_t blas_node_step(const DevScene& S, int32_t cur, const BlasRay& R, float tbest, int* stk, int& sp,
-                                                  LocalCounters& lc, unsigned long long* dbg_loaded = nullptr) {
+                                                  LocalCounters& lc) {
   if (COUNT) lc.blas_nodes++;
   const float4* n = S.blas_nodes + 4 * (size_t)cur;
   float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
-  if (dbg_loaded) {                      // diagnostic builds: when did the node arrive?
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(q0.x), "+v"(q1.x), "+v"(q2.x), "+v"(q3.x) : : "memory");
-    *dbg_loaded = __builtin_amdgcn_s_memtime();
-  }
   return blas_node_eval(q0, q1, q2, q3, R, tbest, stk, sp);
 }
 
@@ -792,7 +788,7 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
   bool watchdog = false;
 #ifdef URT_STAMPS
   unsigned long long ph_t[4] = {0, 0, 0, 0}, ph_lanes[4] = {0, 0, 0, 0}, ph_trips[4] = {0, 0, 0, 0};   // FRONT, BLAS, SHADE, blas inner trips
-  unsigned long long t_begin = wall_clock64(), t_dry = 0, dbg[5] = {0, 0, 0, 0, 0};
+  unsigned long long t_begin = wall_clock64(), t_dry = 0;
   unsigned long long c_begin = __builtin_amdgcn_s_memtime();
 #endif
 
@@ -868,30 +864,12 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
         bool interior = active && cur >= 0;
         int nI = __popcll(__ballot(interior));
         int nL = __popcll(mA) - nI;
-#ifdef URT_STAMPS
-        unsigned long long tq0 = __builtin_amdgcn_s_memtime(), tq1 = tq0;
-        if (nI >= nL) {
-          if (interior) cur = blas_node_step<COUNT>(S, cur, R, best.t, bl, sp, lc, &tq1);
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          unsigned long long tq2 = __builtin_amdgcn_s_memtime();
-          tq1 = __shfl(tq1, __ffsll((long long)__ballot(interior)) - 1, 64);
-          dbg[0]++; dbg[1] += tq1 - tq0; dbg[2] += tq2 - tq1;
-        } else {
-          if (active && !interior) {
-            test_leaf<COUNT>(S, cur, o, d, best, best_i, lc);
-            cur = blas_pop(bl, sp);
-          }
-          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-          dbg[3]++; dbg[4] += __builtin_amdgcn_s_memtime() - tq0;
-        }
-#else
         if (nI >= nL) {
           if (interior) cur = blas_node_step<COUNT>(S, cur, R, best.t, bl, sp, lc);
         } else if (active && !interior) {
           test_leaf<COUNT>(S, cur, o, d, best, best_i, lc);
           cur = blas_pop(bl, sp);
         }
-#endif
         active = mine && cur != kBlasDone;
       }
       // back to the heap walk (RS:323-325 continues) — or, when nothing of Trace() is left to do (empty object-level stack and
@@ -928,7 +906,6 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
     size_t w = ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 32;
     for (int q = 0; q < 4; q++) { sp_[w + q] = ph_t[q]; sp_[w + 4 + q] = ph_lanes[q]; sp_[w + 8 + q] = ph_trips[q]; }
     sp_[w + 12] = t_begin; sp_[w + 13] = wall_clock64(); sp_[w + 14] = t_dry; sp_[w + 15] = __builtin_amdgcn_s_memtime() - c_begin;
-    for (int q = 0; q < 5; q++) sp_[w + 16 + q] = dbg[q];
   }
 #endif
   if (watchdog && (threadIdx.x & 63) == 0) atomicAdd(&ctr->watchdog, 1ull);
