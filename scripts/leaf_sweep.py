@@ -2,9 +2,9 @@ import sys, time
 sys.path.insert(0, '.')
 from unityraytracer_amd import Context, RayTraceMaster, scenes
 ctx = Context(0)
-for cfg in ("C3", "C5"):
+for cfg in ("C3", "C4", "C5", "C3"):
     sc = scenes.CONFIGS[cfg]()
-    for leaf in (1, 2, 4, 6, 8):
+    for leaf in (2, 3, 4, 5):
         ctx.set_option("blas_leaf_max", leaf); ctx.set_option("count_stats", 0); ctx.set_option("time_dispatch", 1)
         m = RayTraceMaster(ctx, sc)
         for _ in range(3): m.OnRenderImage()

@@ -1,0 +1,34 @@
+"""Reduce gpurun_out/prof (scripts/collect_profiles.sh) to the small files kept under profiles/:
+   <prefix>_kernel_stats.csv, <prefix>_pmc.json, pmc_traffic.json, <prefix>_bench.json.log."""
+import csv, glob, json, os, shutil, sys
+src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof"
+prefix = sys.argv[2] if len(sys.argv) > 2 else "r01_bench_c3"
+dst = "profiles"
+KERNEL = "k_sched<false"   # the timed trace kernel (counting replay is k_sched<true ...)
+
+stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
+if stats:
+    shutil.copy(stats[0], os.path.join(dst, f"{prefix}_kernel_stats.csv"))
+    for r in csv.DictReader(open(stats[0])):
+        if KERNEL in r["Name"]: print("kernel stats:", r["Name"][:60], "calls", r["Calls"], "avg ns", r["AverageNs"])
+pmc = {}
+for f in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+    acc = {}
+    for r in csv.DictReader(open(f)):
+        if KERNEL not in r["Kernel_Name"]: continue
+        acc.setdefault(r["Counter_Name"], {}).setdefault(r["Dispatch_Id"], 0.0)
+        acc[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
+    for k, per in acc.items(): pmc[k] = sum(per.values()) / len(per)
+json.dump(pmc, open(os.path.join(dst, f"{prefix}_pmc_k_sched.json"), "w"), indent=1, sort_keys=True)
+print(json.dumps(pmc, indent=1, sort_keys=True))
+if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+    hbm = int(2 * pmc["FETCH_SIZE"] * 1024 + pmc["WRITE_SIZE"] * 1024)
+    json.dump({"config": "C3", "kernel": "k_sched<false, 256, false>", "round": 1, "FETCH_SIZE_KB_per_launch": pmc["FETCH_SIZE"],
+               "WRITE_SIZE_KB_per_launch": pmc["WRITE_SIZE"],
+               "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request -> doubled (MI355X_MICROARCH.md 'HBM'); WRITE_SIZE exact",
+               "hbm_bytes_per_launch": hbm,
+               "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline"},
+              open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+    print("hbm bytes per launch", hbm)
+b = os.path.join(src, "bench.json.log")
+if os.path.exists(b): shutil.copy(b, os.path.join(dst, f"{prefix}_n1.json.log"))

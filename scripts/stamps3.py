@@ -6,7 +6,7 @@ ctx = Context(0)
 lib = _lib.load()
 lib.urt_debug_read_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 import itertools
-for (w, h, b), wpc in itertools.product(((1920, 1080, 8), (3840, 2160, 8)), (20,)):
+for (w, h, b), wpc in itertools.product(((1920, 1080, 8),), (20,)):
     sc = scenes.config3(w, h); sc.num_bounces = b
     ctx.set_option("kernel_mode", 3); ctx.set_option("waves_per_cu", wpc)
     print(f"--- waves/CU {wpc}")
@@ -33,4 +33,11 @@ for (w, h, b), wpc in itertools.product(((1920, 1080, 8), (3840, 2160, 8)), (20,
     for q in range(3):
         print(f"   {names[q]:5s}: {t[:, q].sum() / life.sum() * 100:5.1f} % of wave time, {trips[:, q].mean():7.1f} trips/wave, {lanes[:, q].sum() / max(1, trips[:, q].sum()):5.1f} lanes/trip, {t[:, q].sum() / max(1, trips[:, q].sum()):7.2f} us/trip")
     print(f"   BLAS inner: {trips[:, 3].mean():8.1f} steps/wave, {lanes[:, 3].sum() / max(1, trips[:, 3].sum()):5.1f} active lanes/step, {t[:, 1].sum() / max(1, trips[:, 3].sum()) * 1000:7.1f} ns/step")
+    dr = st[:, 16:25].astype(np.float64)
+    drain = end - dry
+    order = np.argsort(drain)
+    for label, sel in (("all waves", order), ("slowest 5 %", order[-len(order) // 20:])):
+        d = dr[sel]
+        print(f"   drain [{label}]: {drain[sel].mean():.0f} us after dry with {d[:, 7].mean():.1f} live paths; trips FRONT {d[:, 0].mean():.1f} BLAS {d[:, 1].mean():.1f} SHADE {d[:, 2].mean():.1f}; "
+              f"time FRONT {d[:, 4].mean() / 100:.0f} BLAS {d[:, 5].mean() / 100:.0f} SHADE {d[:, 6].mean() / 100:.0f} us; BLAS steps {d[:, 3].mean():.0f} at {d[:, 8].sum() / max(1, d[:, 3].sum()):.1f} lanes")
     m.OnDisable()

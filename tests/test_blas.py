@@ -52,6 +52,29 @@ def validate(scene, nodes, tri_index, mesh_root):
     return max_depth
 
 
+def test_top_of_forest_is_breadth_first(built_library):
+    """Node indices [0, 256) are the top of the forest in breadth-first order (roots of all meshes first): the phase
+    scheduler copies a prefix of the node array to LDS and relies on every parent of a prefix node being in the prefix."""
+    sc = scenes.mixed_test_scene(64, 48, blob=(40, 31))
+    nodes, tri, root, first, depth = debug_build_blas(sc.mesh_objects, sc.vertices, sc.indices)
+    roots = [int(r) for r in root if 0 <= r != 0x7FFFFFFF]
+    assert roots == list(range(len(roots))), "interior roots must be nodes 0..k-1 in MeshObject order"
+    queue, order = list(roots), []
+    while queue and len(order) < 256:
+        n = queue.pop(0)
+        order.append(n)
+        queue += [int(c) for c in nodes[n][12:14].view(np.int32) if c >= 0]
+    assert order == list(range(len(order))), "breadth-first walk must meet nodes 0, 1, 2, ... in order"
+    parent = {}
+    for i, n in enumerate(nodes):
+        for c in n[12:14].view(np.int32):
+            if c >= 0:
+                assert int(c) not in parent, "a node has two parents"
+                parent[int(c)] = i
+    for t in (8, 16, 64, min(256, len(nodes))):
+        assert all(parent[i] < t for i in range(len(roots), min(t, len(nodes)))), f"prefix {t} is not closed under parent"
+
+
 @pytest.mark.parametrize("scene_fn", [lambda: scenes.mixed_test_scene(64, 48), lambda: scenes.config3(64, 36, slices=40, stacks=31, sky=scenes.make_sky(64, 32))])
 def test_product_blas_is_valid(built_library, scene_fn):
     sc = scene_fn()

@@ -75,6 +75,55 @@ def test_config3_mesh_quarter_res_bit_exact(gpu_ctx):
     assert_same(gpu[rect[1]:rect[3], rect[0]:rect[2]], brute, "C3 crop vs brute force")
 
 
+SCHED_VARIANTS = [
+    {"sched_block": 64, "top_nodes": 0, "lds_tlas": 0},
+    {"sched_block": 64, "top_nodes": 8, "top_front": 0},
+    {"sched_block": 64, "top_nodes": 16, "top_front": 1},
+    {"sched_block": 256, "top_nodes": 64, "top_front": 0, "lds_tlas": 0},
+    {"sched_block": 256, "top_nodes": 256, "top_front": 1},
+    {"sched_block": 0, "top_nodes": 64, "top_front": -1, "tile_order": 1, "xcd_run": 5},
+    {"refill_min": 1, "blas_min": 1, "blas_exit": 1, "waves_per_cu": 3},
+    {"refill_min": 64, "blas_min": 64, "blas_exit": 64, "waves_per_cu": 32},
+]
+SCHED_DEFAULTS = {"sched_block": 0, "top_nodes": 64, "top_front": -1, "lds_tlas": 1, "tile_order": 0, "xcd_run": 1,
+                  "refill_min": 32, "blas_min": 28, "blas_exit": 6, "waves_per_cu": 0}
+
+
+@pytest.mark.parametrize("variant", range(len(SCHED_VARIANTS)))
+def test_scheduler_variants_do_not_change_pixels_or_counters(gpu_ctx, variant):
+    """Workgroup shape, the LDS copies (BVH top, object-level tables), where the top is walked, tile order and the voting
+    thresholds only decide WHEN and WHERE a pixel's operations run: same pixels, same traversal counters."""
+    sc = scenes.mixed_test_scene(200, 120, blob=(40, 31))     # a blob deep enough to have > 256 BVH nodes
+    o = oracle_for(sc)
+    ref, oc = o.render(mode=1, threads=8, counters=True)
+    try:
+        for k, v in SCHED_VARIANTS[variant].items():
+            gpu_ctx.set_option(k, v)
+        gpu, _, gc = render_gpu(gpu_ctx, sc, 3, count=True)
+    finally:
+        for k, v in SCHED_DEFAULTS.items():
+            gpu_ctx.set_option(k, v)
+    assert_same(gpu, ref, f"scheduler variant {SCHED_VARIANTS[variant]}")
+    for k in ("rays", "tlas_nodes", "blas_nodes", "tri_tests", "sphere_tests", "hit_tri", "hit_sphere", "hit_ground", "hit_sky", "pixels"):
+        assert gc[k] == oc[k], (k, gc[k], oc[k])
+    assert gc["watchdog_trips"] == 0
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4])
+def test_path_pool_sizes_bit_exact(gpu_ctx, k):
+    sc = scenes.mixed_test_scene(200, 120)
+    sc.num_rays = 2
+    ref = oracle_for(sc).render(mode=1, threads=8)
+    try:
+        gpu_ctx.set_option("pool_k", k)
+        gpu_ctx.set_option("pool_blas_exit", 16 if k > 1 else 8)
+        gpu, _, gc = render_gpu(gpu_ctx, sc, 4, count=True)
+    finally:
+        gpu_ctx.set_option("pool_k", 2); gpu_ctx.set_option("pool_blas_exit", 8)
+    assert_same(gpu, ref, f"path pool K={k}, 2 rays per pixel")
+    assert gc["watchdog_trips"] == 0
+
+
 def test_multi_ray_multi_frame_accumulation(gpu_ctx):
     sc = scenes.mixed_test_scene(96, 64)
     sc.num_rays, sc.num_bounces = 3, 5
@@ -84,7 +133,7 @@ def test_multi_ray_multi_frame_accumulation(gpu_ctx):
         ox, oy, seed = scenes.frame_uniforms(f)
         o.set_frame((ox, oy), seed)
         conv_ref = pyoracle.accumulate(o.render(mode=1, threads=8), conv_ref, f)
-    for mode in (0, 1, 2, 3):
+    for mode in (0, 1, 2, 3, 4):
         _, conv, _ = render_gpu(gpu_ctx, sc, mode, frames=3)
         assert_same(conv, conv_ref, f"3-frame running mean, mode {mode}")
 

@@ -557,7 +557,9 @@ __device__ __forceinline__ bool wave_fetch_pixels(const FrameParams& P, unsigned
   }
   unsigned int local = base + (unsigned int)__popcll(want & ((1ull << lane) - 1ull));
   if (!mine || local >= own) return false;
-  return slot_pixel(P, shard_tile(shard, local >> 6, G), local & 63u, x, y);
+  unsigned int tile = shard_tile(shard, local >> 6, G);
+  if (P.tile_order == 1) tile = ntiles - 1u - tile;            // top strip first
+  return slot_pixel(P, tile, local & 63u, x, y);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -790,6 +792,7 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
   unsigned long long ph_t[4] = {0, 0, 0, 0}, ph_lanes[4] = {0, 0, 0, 0}, ph_trips[4] = {0, 0, 0, 0};   // FRONT, BLAS, SHADE, blas inner trips
   unsigned long long t_begin = wall_clock64(), t_dry = 0;
   unsigned long long c_begin = __builtin_amdgcn_s_memtime();
+  unsigned long long dr_trips[4] = {0, 0, 0, 0}, dr_t[3] = {0, 0, 0}, dr_live = 0, dr_lanes3 = 0;   // after the work ran dry
 #endif
 
   for (;;) {
@@ -830,6 +833,7 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
     int ph_id = phase == ST_FRONT ? 0 : phase == ST_BLAS ? 1 : 2;
     ph_lanes[ph_id] += (unsigned long long)(phase == ST_FRONT ? nF : phase == ST_BLAS ? nB : nS);
     ph_trips[ph_id]++;
+    if (exhausted) { if (!dr_live) dr_live = 64 - nD; dr_trips[ph_id]++; }
 #endif
     if (phase == ST_FRONT) {
       // ---------------- FRONT / RESUME: Trace() up to the next triangle-BVH visit (RS:364-383) ----------------
@@ -858,6 +862,7 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
         if (++steps > P.watchdog_steps) { watchdog = true; break; }
 #ifdef URT_STAMPS
         ph_trips[3]++; ph_lanes[3] += (unsigned long long)__popcll(mA);
+        if (exhausted) { dr_trips[3]++; dr_lanes3 += (unsigned long long)__popcll(mA); }
 #endif
         // majority vote: this trip runs EITHER the interior-node step OR the leaf step, for the lanes that hold that kind
         // of cursor (the others wait one trip) — so a trip costs one of the two bodies, not their sum.
@@ -898,12 +903,16 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
     }
 #ifdef URT_STAMPS
     ph_t[ph_id] += wall_clock64() - t_ph;
+    if (exhausted) dr_t[ph_id] += wall_clock64() - t_ph;
 #endif
   }
 #ifdef URT_STAMPS
   if ((threadIdx.x & 63) == 0) {
     unsigned long long* sp_ = (unsigned long long*)(next + kWorkShards * 32);
     size_t w = ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 32;
+    for (int q = 0; q < 4; q++) sp_[w + 16 + q] = dr_trips[q];
+    for (int q = 0; q < 3; q++) sp_[w + 20 + q] = dr_t[q];
+    sp_[w + 23] = dr_live; sp_[w + 24] = dr_lanes3;
     for (int q = 0; q < 4; q++) { sp_[w + q] = ph_t[q]; sp_[w + 4 + q] = ph_lanes[q]; sp_[w + 8 + q] = ph_trips[q]; }
     sp_[w + 12] = t_begin; sp_[w + 13] = wall_clock64(); sp_[w + 14] = t_dry; sp_[w + 15] = __builtin_amdgcn_s_memtime() - c_begin;
   }

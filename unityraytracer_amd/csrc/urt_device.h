@@ -51,6 +51,7 @@ struct FrameParams {
   int tlas_stack;           // LDS entries per lane reserved for the object-level stacks
   int blas_stack;           // LDS entries per lane reserved for the triangle-BVH stack
   int block_threads;        // workgroup size (64, 128 or 256)
+  int tile_order;           // persistent modes: 0 = strips bottom to top (natural), 1 = top to bottom
   int xcd_run;              // blocks per XCD run in the tile order (kernels.hip tile_pixel)
   int refill_min;           // persistent modes: dead lanes per wave that trigger a refill (1..64)
   int blas_min;             // mode 3: lanes parked in BLAS before the traversal phase is scheduled (1..64)
