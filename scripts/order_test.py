@@ -14,6 +14,6 @@ def run(sc, opts, frames=8):
 for rep in range(2):
     for name in (sys.argv[1:] or ["C3", "C3@4K", "C4", "C5", "C2"]):
         sc = scenes.config3(3840, 2160) if name == "C3@4K" else scenes.CONFIGS[name]()
-        for order in (0, 1):
-            ms, wd = run(sc, {"kernel_mode": 3, "drain_both": order}, frames=4 if name in ("C4", "C5") else 8)
-            print(f"{name:6s} drain_both {order}: {ms:8.3f} ms wd {wd}", flush=True)
+        for order in (1, 8, 16, 24, 32, 48):
+            ms, wd = run(sc, {"kernel_mode": 3, "shade_min": order}, frames=4 if name in ("C4", "C5") else 8)
+            print(f"{name:6s} shade_min {order:2d}: {ms:8.3f} ms wd {wd}", flush=True)

@@ -822,8 +822,9 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
     int phase;
     int exit_below = 1;              // traversal runs to completion unless other lanes can make progress meanwhile
     if (nB >= P.blas_min) { phase = ST_BLAS; if (nS + nF > 0 || can_refill) exit_below = min(P.blas_exit, nB); }   // <= nB: the phase always advances a lane
+    else if (nS >= P.shade_min) phase = ST_SHADE;   // SHADE is the longest straight-line code (~1100 VALU whatever the lane count):
+    else if (nF > 0) phase = ST_FRONT;              // a thin batch waits while the cheap FRONT phase can still feed it
     else if (nS > 0) phase = ST_SHADE;
-    else if (nF > 0) phase = ST_FRONT;
     else if (nB > 0) phase = ST_BLAS;
     else if (exhausted) break;       // every lane dead and no work left
     else continue;                   // every fetched slot fell outside the region: fetch again

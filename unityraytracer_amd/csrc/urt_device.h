@@ -55,6 +55,7 @@ struct FrameParams {
   int xcd_run;              // blocks per XCD run in the tile order (kernels.hip tile_pixel)
   int refill_min;           // persistent modes: dead lanes per wave that trigger a refill (1..64)
   int blas_min;             // mode 3: lanes parked in BLAS before the traversal phase is scheduled (1..64)
+  int shade_min;            // mode 3: SHADE lanes that make the phase run ahead of FRONT (1..64)
   int blas_exit;            // mode 3: the traversal phase yields when fewer lanes than this are still traversing (1..64)
   int top_nodes;            // mode 3: triangle-BVH nodes [0, top_nodes) are copied to LDS (breadth-first top of the forest); 0 = none
   int lds_mesh, lds_sphere; // mode 3: keep the object-level mesh heap + roots / sphere heap + spheres in LDS (0/1)
