@@ -230,7 +230,7 @@ def main():
                     traffic = j.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        roofline = {"bound": "hbm", "kernel": "trace: k_sched (kernel_mode 3; 2 = k_persist, 0 = k_mega, 1 = k_bounce)", "achieved": round(achieved, 1),
+        roofline = {"bound": "hbm", "kernel": "trace: k_sched<false,256,false> (kernel_mode 3, the default)" if args.kernel_mode in (None, 3) else f"trace kernel of kernel_mode {args.kernel_mode}", "achieved": round(achieved, 1),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "algorithmic_bytes_per_launch": int(alg), "kernel_ms": round(kernel_ms, 4),
                     "bytes_per_ray": round(alg * cc["dispatches"] / max(1, cc["rays"]), 1)}

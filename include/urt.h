@@ -146,9 +146,16 @@ typedef struct urt_counters {
  *          "time_dispatch" (0/1: bracket each dispatch with HIP events, read by urt_get_counters),
  *          "kernel_mode" (0 = one thread per pixel; 1 = one launch per bounce over compacted path queues;
  *                         2 = persistent waves with in-wave path regeneration;
- *                         3 = 2 + lanes scheduled by phase inside the wave, the default),
- *          "block_threads" (64 | 128 | 256), "xcd_run" (>= 1), "refill_min" (1..64), "waves_per_cu" (0 = auto, 1..32),
- *          "blas_min" / "blas_exit" (1..64, mode 3)
+ *                         3 = 2 + lanes scheduled by phase inside the wave, the default;
+ *                         4 = 3 with a pool of 64 x pool_k paths per wave kept in LDS, experimental),
+ *          "block_threads" (64 | 128 | 256: modes 0-2), "xcd_run" (>= 1: run length of the tile order),
+ *          "tile_order" (0 bottom-up | 1 top-down), "waves_per_cu" (0 = auto, 1..32), "refill_min" (1..64),
+ *          mode 3: "blas_min" / "blas_exit" / "shade_min" (1..64: vote thresholds), "sched_block" (0 auto | 64 | 256),
+ *                  "top_nodes" (0..256 triangle-BVH nodes kept in LDS), "top_front" (-1 auto | 0 | 1: where that top is
+ *                  walked), "lds_tlas" (0/1: small object-level tables in LDS),
+ *          mode 4: "pool_k" (1..4), "pool_refill", "pool_blas_min" (1..256), "pool_blas_exit", "pool_inloop",
+ *                  "pool_other_min" (1..64),
+ *          "blas_leaf_max" (1..8: triangles per BVH leaf; rebuilds the BVH)
  *          — tuning knobs; they change speed only, never pixels. */
 URT_API int urt_set_option(urt_context* ctx, const char* name, int value);
 URT_API int urt_get_counters(urt_context* ctx, urt_counters* out);   /* synchronises */
