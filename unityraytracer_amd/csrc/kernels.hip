@@ -286,6 +286,14 @@ __device__ __forceinline__ v3 sample_hemisphere(v3 normal, float alpha, float& s
              f_fma(ts.z, normal.z, f_fma(ts.y, binormal.z, ts.x * tangent.z)));
 }
 
+// The result image is written once per pixel and not read by this kernel: stored non-temporally so that it does not push
+// BVH lines out of the L2 (measured -1 %; the same hint on the sky's texel loads costs +3 % and is not used).
+typedef float f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st_result(float4* p, float4 v) {
+  f4v q = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(q, (f4v*)p);
+}
+
 __device__ __forceinline__ v3 sample_sky(const DevScene& S, float u, float v) {
   int W = S.sky_w, H = S.sky_h;
   float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
@@ -495,7 +503,7 @@ __global__ __launch_bounds__(256) void k_mega(DevScene S, FrameParams P, float4*
       avg = avg + res;
     }
     float n = (float)P.num_rays;
-    result[(size_t)y * P.width + x] = make_float4(avg.x / n, avg.y / n, avg.z / n, 1.0f);
+    st_result(result + (size_t)y * P.width + x, make_float4(avg.x / n, avg.y / n, avg.z / n, 1.0f));
   }
   flush_counters<COUNT>(lc, ctr);
 }
@@ -622,7 +630,7 @@ __global__ __launch_bounds__(256) void k_persist(DevScene S, FrameParams P, floa
           camera_ray<kPOffAfterScene>(P, x, y, seed, o, d);
         } else {
           float n = (float)P.num_rays;
-          result[(size_t)y * P.width + x] = make_float4(avg.x / n, avg.y / n, avg.z / n, 1.0f);   // RS:468
+          st_result(result + (size_t)y * P.width + x, make_float4(avg.x / n, avg.y / n, avg.z / n, 1.0f));   // RS:468
           alive = false;
         }
       }
@@ -896,7 +904,7 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
             camera_ray<kPOffAfterScene>(P, x, y, seed, o, d);
           } else {
             float n = (float)P.num_rays;
-            result[(size_t)y * P.width + x] = make_float4(avg.x / n, avg.y / n, avg.z / n, 1.0f);
+            st_result(result + (size_t)y * P.width + x, make_float4(avg.x / n, avg.y / n, avg.z / n, 1.0f));
             st = ST_DEAD;
           }
         }
@@ -1165,7 +1173,7 @@ __global__ __launch_bounds__(64) void k_pool(DevScene S, FrameParams P, float4* 
             if (multi) { PFset(F_AX, mine, avg.x); PFset(F_AY, mine, avg.y); PFset(F_AZ, mine, avg.z); }
           } else {
             float n = (float)P.num_rays;
-            result[(size_t)y * P.width + x] = make_float4(avg.x / n, avg.y / n, avg.z / n, 1.0f);
+            st_result(result + (size_t)y * P.width + x, make_float4(avg.x / n, avg.y / n, avg.z / n, 1.0f));
             nst = PS_FREE;
           }
         }
