@@ -109,6 +109,27 @@ def test_scheduler_variants_do_not_change_pixels_or_counters(gpu_ctx, variant):
     assert gc["watchdog_trips"] == 0
 
 
+def test_many_meshes_beyond_the_lds_tables(gpu_ctx):
+    """300 MeshObjects: a 1023-node object-level heap (more than the 256 entries kept in LDS) and BVH roots on both sides of
+    every `top_nodes` prefix — the LDS copies and their global-memory fallbacks must agree, in every kernel mode."""
+    sc = scenes.many_meshes_scene(128, 80)
+    o = oracle_for(sc)
+    ref, oc = o.render(mode=1, threads=8, counters=True)
+    for mode in (0, 1, 2, 3, 4):
+        gpu, _, gc = render_gpu(gpu_ctx, sc, mode, count=True)
+        assert_same(gpu, ref, f"many meshes, mode {mode}")
+        for k in ("rays", "tlas_nodes", "blas_nodes", "tri_tests", "hit_tri", "hit_ground", "hit_sky", "pixels"):
+            assert gc[k] == oc[k], (mode, k, gc[k], oc[k])
+    try:
+        for tn, tf in ((256, 1), (256, 0), (32, 1), (1, 1), (0, 0)):
+            gpu_ctx.set_option("top_nodes", tn); gpu_ctx.set_option("top_front", tf)
+            gpu, _, gc = render_gpu(gpu_ctx, sc, 3, count=True)
+            assert_same(gpu, ref, f"many meshes, top_nodes {tn} top_front {tf}")
+            assert gc["blas_nodes"] == oc["blas_nodes"] and gc["tri_tests"] == oc["tri_tests"] and gc["watchdog_trips"] == 0
+    finally:
+        gpu_ctx.set_option("top_nodes", 64); gpu_ctx.set_option("top_front", -1)
+
+
 @pytest.mark.parametrize("k", [1, 2, 3, 4])
 def test_path_pool_sizes_bit_exact(gpu_ctx, k):
     sc = scenes.mixed_test_scene(200, 120)

@@ -505,4 +505,26 @@ def mixed_test_scene(width=96, height=64, n_spheres=5, blob=(12, 9), sky=None) -
                  sphere_bvh=build_object_bvh(*sphere_bounds(sp)), sky=sky if sky is not None else make_sky(128, 64))
 
 
+def many_meshes_scene(width=128, height=80, n=300, level=0, sky=None) -> Scene:
+    """n small MeshObjects (icospheres of 20 * 4^level triangles: each has interior BVH nodes) on a jittered grid: more
+    object-level heap nodes (511 for n = 300) and more BVH roots than the library keeps in LDS — exercises the paths
+    that fall back to global memory."""
+    rng = SplitMix64(0xA11CE)
+    b = MeshSceneBuilder()
+    v, t = icosphere(level)
+    side = int(math.ceil(math.sqrt(n)))
+    for i in range(n):
+        gx, gz = i % side, i // side
+        x = (gx - side / 2.0) * 1.3 + 0.4 * (rng.value() - 0.5)
+        z = (gz - side / 2.0) * 1.3 + 4.0 + 0.4 * (rng.value() - 0.5)
+        r = 0.35 + 0.25 * rng.value()
+        col = (rng.value(), rng.value(), rng.value())
+        metal = i % 3 == 0
+        lighting = _params((0, 0, 0) if metal else col, col if metal else (0.04, 0.04, 0.04), (2.0, 1.5, 1.0) if i % 17 == 0 else (0, 0, 0), rng.value())
+        b.add(v, t, trs(translate=(x, r, z), scale=r, yaw_deg=360.0 * rng.value()), lighting)
+    mo, vv, ii, nn, bvh = b.finish()
+    return Scene(f"many-meshes{n}", width, height, 4, 1, mesh_objects=mo, vertices=vv, indices=ii, normals=nn, mesh_bvh=bvh,
+                 sky=sky if sky is not None else make_sky(128, 64))
+
+
 CONFIGS = {"C1": config1, "C2": config2, "C3": config3, "C4": config4, "C5": config5}
