@@ -52,6 +52,22 @@ def validate(scene, nodes, tri_index, mesh_root):
     return max_depth
 
 
+def test_parallel_build_is_deterministic(built_library):
+    """MeshObjects are built on several host threads and concatenated in MeshObject order: the BVH must not depend on the
+    thread count (URT_BLAS_THREADS overrides it for this test)."""
+    import hashlib, os, subprocess, sys
+    code = ("import sys, hashlib; sys.path.insert(0, %r)\n"
+            "from unityraytracer_amd import scenes, debug_build_blas\n"
+            "sc = scenes.many_meshes_scene(n=40, level=2)\n"
+            "r = debug_build_blas(sc.mesh_objects, sc.vertices, sc.indices)\n"
+            "print(hashlib.sha256(b''.join(a.tobytes() for a in r[:4])).hexdigest(), r[4])\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for threads in ("1", "2", "7"):
+        env = dict(os.environ, URT_BLAS_THREADS=threads)
+        outs.append(subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.strip())
+    assert outs[0] == outs[1] == outs[2] and len(outs[0]) > 64
+
+
 def test_top_of_forest_is_breadth_first(built_library):
     """Node indices [0, 256) are the top of the forest in breadth-first order (roots of all meshes first): the phase
     scheduler copies a prefix of the node array to LDS and relies on every parent of a prefix node being in the prefix."""

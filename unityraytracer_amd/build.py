@@ -13,7 +13,7 @@ LIB = os.path.join(_HERE, "libunityraytracer_amd.so")
 HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17",
     "-ffp-contract=off",            # normative arithmetic: no implicit fma (include/urt_math.h)
-    "-fPIC", "-shared", "-fvisibility=hidden",
+    "-fPIC", "-shared", "-fvisibility=hidden", "-pthread",
     "-Xarch_host", "-march=x86-64-v3",   # inline hardware fma for the host-side vertex pre-transform
     "-Wall", "-Wno-unused-function",
 ]

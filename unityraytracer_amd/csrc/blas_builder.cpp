@@ -16,8 +16,11 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <limits>
+#include <thread>
 
 #include "../../include/urt_math.h"
 
@@ -47,15 +50,18 @@ constexpr int kLeafHardMax = 8;  // encoding limit (3 bits)
 
 struct Builder {
   std::vector<Prim> prims;
-  BlasResult& out;
+  // output of ONE mesh, in mesh-local numbering (node indices and leaf-order triangle slots start at 0): meshes are built
+  // independently (in parallel) and concatenated afterwards
+  std::vector<float> nodes;
+  std::vector<int32_t> tri_slot;
+  int32_t root = kEmptyMeshRoot;
   float pad = 0;
-  int mesh_id = 0;
   int max_depth = 0;
-  explicit Builder(BlasResult& o) : out(o) {}
+  std::string err;
 
   int32_t make_leaf(int lo, int hi) {
-    uint32_t first = (uint32_t)out.tri_slot.size();
-    for (int q = lo; q < hi; q++) { out.tri_slot.push_back(prims[q].slot); out.tri_mesh.push_back(mesh_id); }
+    uint32_t first = (uint32_t)tri_slot.size();
+    for (int q = lo; q < hi; q++) tri_slot.push_back(prims[q].slot);
     uint32_t code = (first << 3) | (uint32_t)(hi - lo - 1);
     return (int32_t)~code;
   }
@@ -114,12 +120,12 @@ struct Builder {
       if (n <= kLeafHardMax && best_axis < 0) return make_leaf(lo, hi);
       mid = (lo + hi) / 2;   // median by current order: keeps the tree finite for degenerate input
     }
-    int32_t me = (int32_t)(out.nodes.size() / kBlasNodeFloats);
-    out.nodes.resize(out.nodes.size() + kBlasNodeFloats, 0.0f);
+    int32_t me = (int32_t)(nodes.size() / kBlasNodeFloats);
+    nodes.resize(nodes.size() + kBlasNodeFloats, 0.0f);
     Box b0, b1;
     int32_t c0 = build(lo, mid, depth + 1, b0);
     int32_t c1 = build(mid, hi, depth + 1, b1);
-    float* nd = out.nodes.data() + (size_t)me * kBlasNodeFloats;
+    float* nd = nodes.data() + (size_t)me * kBlasNodeFloats;
     for (int k = 0; k < 3; k++) {
       nd[k] = b0.lo[k] - pad; nd[3 + k] = b0.hi[k] + pad;
       nd[6 + k] = b1.lo[k] - pad; nd[9 + k] = b1.hi[k] + pad;
@@ -140,16 +146,18 @@ bool build_blas(const uint8_t* mesh_objects, int n_meshes, const float* vertices
   out = BlasResult();
   out.mesh_root.assign((size_t)n_meshes, kEmptyMeshRoot);
   out.mesh_first_tri.assign((size_t)n_meshes, 0);
-  for (int m = 0; m < n_meshes; m++) {
+  // one independent build per MeshObject, spread over the host's cores; concatenated in MeshObject order afterwards, so the
+  // result does not depend on the number of threads
+  std::vector<Builder> builds((size_t)n_meshes);
+  auto build_one = [&](int m) {
+    Builder& B = builds[(size_t)m];
     urt_MeshObject mo;
     std::memcpy(&mo, mesh_objects + (size_t)m * sizeof(urt_MeshObject), sizeof mo);
     long off = mo.indices_offset, cnt = mo.indices_count;
     if (off < 0 || cnt < 0 || off + cnt > n_indices) {
-      err = "MeshObject " + std::to_string(m) + ": indices_offset/count outside _Indices";
-      return false;
+      B.err = "MeshObject " + std::to_string(m) + ": indices_offset/count outside _Indices";
+      return;
     }
-    Builder B(out);
-    B.mesh_id = m;
     float ext = 0;
     B.prims.reserve((size_t)(cnt / 3));
     for (long i = off; i + 2 < off + cnt; i += 3) {
@@ -158,8 +166,8 @@ bool build_blas(const uint8_t* mesh_objects, int n_meshes, const float* vertices
       for (int j = 0; j < 3; j++) {
         int32_t vi = indices[i + j];
         if (vi < 0 || vi >= n_vertices || (normals && vi >= n_normals)) {
-          err = "_Indices[" + std::to_string(i + j) + "] = " + std::to_string(vi) + " is outside _Vertices/_Normals";
-          return false;
+          B.err = "_Indices[" + std::to_string(i + j) + "] = " + std::to_string(vi) + " is outside _Vertices/_Normals";
+          return;
         }
         const float* v = vertices + 3 * (size_t)vi;
         urt::v3 w = urt::mul_m4(mo.localToWorldMatrix, v[0], v[1], v[2], 1.0f);
@@ -172,12 +180,45 @@ bool build_blas(const uint8_t* mesh_objects, int n_meshes, const float* vertices
       for (int k = 0; k < 3; k++) p.c[k] = 0.5f * p.lo[k] + 0.5f * p.hi[k];
       B.prims.push_back(p);
     }
-    out.mesh_first_tri[(size_t)m] = (int32_t)out.tri_slot.size();
-    if (B.prims.empty()) continue;
+    if (B.prims.empty()) return;
     B.pad = ext * 1.52587890625e-5f + 1e-30f;
     Box root;
-    out.mesh_root[(size_t)m] = B.build(0, (int)B.prims.size(), 1, root);
+    B.root = B.build(0, (int)B.prims.size(), 1, root);
+    std::vector<Prim>().swap(B.prims);
+  };
+  {
+    unsigned hw = std::thread::hardware_concurrency();
+    int n_threads = (int)std::min<size_t>(std::min<size_t>(hw ? hw : 1, 16), (size_t)std::max(1, n_meshes));
+    if (n_indices < 30000) n_threads = 1;                       // small scenes: not worth starting threads
+    if (const char* e = std::getenv("URT_BLAS_THREADS")) { int v = std::atoi(e); if (v >= 1) n_threads = std::min(v, 64); }   // tests
+    std::atomic<int> next_mesh(0);
+    auto worker = [&]() { for (int m; (m = next_mesh.fetch_add(1)) < n_meshes;) build_one(m); };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < n_threads; t++) pool.emplace_back(worker);
+    worker();
+    for (auto& th : pool) th.join();
+  }
+  for (int m = 0; m < n_meshes; m++) {
+    Builder& B = builds[(size_t)m];
+    if (!B.err.empty()) { err = B.err; return false; }         // the first MeshObject in error, as a sequential build reports
+    int32_t node_base = (int32_t)(out.nodes.size() / kBlasNodeFloats);
+    uint32_t tri_base = (uint32_t)out.tri_slot.size();
+    out.mesh_first_tri[(size_t)m] = (int32_t)tri_base;
+    auto rebase = [&](int32_t code) -> int32_t {
+      if (code == kEmptyMeshRoot) return code;
+      if (code >= 0) return code + node_base;
+      uint32_t c = ~(uint32_t)code;
+      return (int32_t)~((((c >> 3) + tri_base) << 3) | (c & 7u));
+    };
+    size_t at = out.nodes.size();
+    out.nodes.insert(out.nodes.end(), B.nodes.begin(), B.nodes.end());
+    for (size_t k = at; k < out.nodes.size(); k += kBlasNodeFloats)
+      for (int c = 0; c < 2; c++) out.nodes[k + 12 + c] = urt::bits_f((uint32_t)rebase((int32_t)urt::f_bits(out.nodes[k + 12 + c])));
+    out.tri_slot.insert(out.tri_slot.end(), B.tri_slot.begin(), B.tri_slot.end());
+    out.tri_mesh.insert(out.tri_mesh.end(), B.tri_slot.size(), m);
+    out.mesh_root[(size_t)m] = rebase(B.root);
     out.max_depth = std::max(out.max_depth, B.max_depth);
+    B = Builder();
   }
   // Renumber the interior nodes so that the first kTopOrderNodes indices are the TOP of the forest in breadth-first order
   // (all roots, then their children, ...): the phase-scheduled kernel keeps nodes [0, T) in LDS and walks them before a ray
@@ -209,28 +250,39 @@ bool build_blas(const uint8_t* mesh_objects, int n_meshes, const float* vertices
   size_t nt = out.tri_slot.size();
   out.tri_verts.assign(nt * 12, 0.0f);
   out.tri_norms.assign(nt * 12, 0.0f);
-  for (size_t k = 0; k < nt; k++) {
-    int32_t i = out.tri_slot[k];
-    int32_t m = out.tri_mesh[k];
-    urt_MeshObject mo;
-    std::memcpy(&mo, mesh_objects + (size_t)m * sizeof(urt_MeshObject), sizeof mo);
-    urt::v3 w[3];
-    for (int j = 0; j < 3; j++) {
-      const float* v = vertices + 3 * (size_t)indices[i + j];
-      w[j] = urt::mul_m4(mo.localToWorldMatrix, v[0], v[1], v[2], 1.0f);      // RS:244-246
-    }
-    urt::v3 e1 = w[1] - w[0], e2 = w[2] - w[0];                                // RS:201-202
-    float* tv = out.tri_verts.data() + 12 * k;
-    tv[0] = w[0].x; tv[1] = w[0].y; tv[2] = w[0].z; tv[3] = urt::bits_f((uint32_t)i);
-    tv[4] = e1.x; tv[5] = e1.y; tv[6] = e1.z; tv[7] = urt::bits_f((uint32_t)m);
-    tv[8] = e2.x; tv[9] = e2.y; tv[10] = e2.z; tv[11] = 0.0f;
-    float* tn = out.tri_norms.data() + 12 * k;
-    if (normals) {
+  auto records = [&](size_t k0, size_t k1) {
+    for (size_t k = k0; k < k1; k++) {
+      int32_t i = out.tri_slot[k];
+      int32_t m = out.tri_mesh[k];
+      urt_MeshObject mo;
+      std::memcpy(&mo, mesh_objects + (size_t)m * sizeof(urt_MeshObject), sizeof mo);
+      urt::v3 w[3];
       for (int j = 0; j < 3; j++) {
-        const float* nn = normals + 3 * (size_t)indices[i + j];              // RS:259-261
-        tn[4 * j] = nn[0]; tn[4 * j + 1] = nn[1]; tn[4 * j + 2] = nn[2];
+        const float* v = vertices + 3 * (size_t)indices[i + j];
+        w[j] = urt::mul_m4(mo.localToWorldMatrix, v[0], v[1], v[2], 1.0f);      // RS:244-246
+      }
+      urt::v3 e1 = w[1] - w[0], e2 = w[2] - w[0];                                // RS:201-202
+      float* tv = out.tri_verts.data() + 12 * k;
+      tv[0] = w[0].x; tv[1] = w[0].y; tv[2] = w[0].z; tv[3] = urt::bits_f((uint32_t)i);
+      tv[4] = e1.x; tv[5] = e1.y; tv[6] = e1.z; tv[7] = urt::bits_f((uint32_t)m);
+      tv[8] = e2.x; tv[9] = e2.y; tv[10] = e2.z; tv[11] = 0.0f;
+      float* tn = out.tri_norms.data() + 12 * k;
+      if (normals) {
+        for (int j = 0; j < 3; j++) {
+          const float* nn = normals + 3 * (size_t)indices[i + j];              // RS:259-261
+          tn[4 * j] = nn[0]; tn[4 * j + 1] = nn[1]; tn[4 * j + 2] = nn[2];
+        }
       }
     }
+  };
+  {
+    int n_threads = nt >= 20000 ? (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u) : 1;
+    if (const char* e = std::getenv("URT_BLAS_THREADS")) { int v = std::atoi(e); if (v >= 1) n_threads = std::min(v, 64); }
+    size_t chunk = (nt + (size_t)n_threads - 1) / (size_t)n_threads;
+    std::vector<std::thread> pool;
+    for (int t = 1; t < n_threads; t++) pool.emplace_back(records, std::min(nt, (size_t)t * chunk), std::min(nt, (size_t)(t + 1) * chunk));
+    records(0, std::min(nt, chunk));
+    for (auto& th : pool) th.join();
   }
   return true;
 }
