@@ -116,7 +116,7 @@ def main():
 
     # ---- multi-GPU frame-end gather, software-pipelined ---------------------------------------------------------------
     # Frame i's strips are packed on the render stream; the ONE collective of the frame (gather to rank 0) runs on a second
-    # stream and overlaps with the rendering of frame i+1; rank 0 de-interleaves frame i while it renders frame i+1.
+    # stream and overlaps with the rendering of frame i+1; rank 0 de-interleaves frame i on that second stream as well.
     # Buffers are double-buffered and every reuse is ordered by events.  URT_BENCH_NO_OVERLAP=1 serialises everything.
     overlap = world > 1 and os.environ.get("URT_BENCH_NO_OVERLAP") != "1"
     if world > 1:
@@ -155,27 +155,27 @@ def main():
         i = state["i"]
         slot = i % 2
         if i >= 2:
-            main_stream.wait_event(ev_gather[slot])                       # the gather of frame i-2 has finished reading packed[slot]
+            main_stream.wait_event(ev_gather[slot])                       # frame i-2's gather (and de-interleave) are done with this slot
         master._converged.pack_rows(rank, world, packed[slot].data_ptr())
         ev_pack[slot].record(main_stream)
         with torch.cuda.stream(comm_stream):
             comm_stream.wait_event(ev_pack[slot])
             do_gather(slot)
+            if rank == 0:
+                # de-interleave on the communication stream too: rank 0's render stream carries the same work as every
+                # other rank's (trace + accumulate + pack) and frame i+1 renders while frame i is gathered and unpacked
+                ctx.set_stream(comm_stream.cuda_stream)
+                unpack(slot)
+                ctx.set_stream(main_stream.cuda_stream)
             ev_gather[slot].record(comm_stream)
-        if overlap:
-            if state["pending"] is not None:                              # de-interleave frame i-1 while frame i's gather is in flight
-                main_stream.wait_event(ev_gather[state["pending"]])
-                unpack(state["pending"])
-            state["pending"] = slot
-        else:
+        if not overlap:
             main_stream.wait_event(ev_gather[slot])
-            unpack(slot)
+        state["pending"] = slot
         state["i"] = i + 1
 
     def drain():
-        if world > 1 and overlap and state["pending"] is not None:
-            main_stream.wait_event(ev_gather[state["pending"]])
-            unpack(state["pending"])
+        if world > 1 and state["pending"] is not None:
+            main_stream.wait_event(ev_gather[0]); main_stream.wait_event(ev_gather[1])
             state["pending"] = None
 
     def fence():
