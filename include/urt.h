@@ -202,6 +202,10 @@ URT_API int urt_debug_build_blas(const void* mesh_objects, int n_meshes, const f
  * index-slot numbers (i of RS:243) in leaf order; mesh_root / mesh_first_tri = one entry per MeshObject.
  * Any pointer may be NULL. */
 URT_API int urt_debug_get_blas(float* nodes, int32_t* tri_index, int32_t* mesh_root, int32_t* mesh_first_tri);
+/* Scene preparation of a context keeps the triangle BVH of every MeshObject and reuses it at the next preparation when the
+ * MeshObject's matrix and the positions behind its index slots are unchanged (the reference re-uploads every buffer when
+ * any object moves, RM:262-336).  Reports how many MeshObject BVHs were reused / built since the context was created. */
+URT_API int urt_debug_blas_cache_stats(urt_context* ctx, uint64_t* out_reused, uint64_t* out_built);
 
 #ifdef __cplusplus
 }

@@ -107,6 +107,36 @@ def test_setdata_after_bind_is_picked_up(gpu_ctx):
     m.OnDisable()
 
 
+def test_moving_one_mesh_rebuilds_only_its_bvh(gpu_ctx):
+    """The reference re-uploads every buffer when one object moves (RM:262-336).  The library then rebuilds the triangle BVH
+    of the MeshObjects that changed only — and the frame is the same as if everything had been rebuilt."""
+    from unityraytracer_amd import debug_build_blas
+    sc = scenes.mixed_test_scene(96, 64)
+    m = RayTraceMaster(gpu_ctx, sc)
+    m.OnRenderImage()
+    reused0, built0 = gpu_ctx.blas_cache_stats()
+    n = len(sc.mesh_objects)
+    mo = sc.mesh_objects.copy()
+    mat = np.asarray(mo[1]["localToWorldMatrix"], np.float32).copy()
+    mat[12] += 0.75; mat[13] += 0.25                          # column-major translation of MeshObject 1
+    mo[1]["localToWorldMatrix"] = mat
+    sc.mesh_objects = mo
+    lo, hi = scenes.mesh_bounds(mo, sc.vertices, sc.indices)
+    sc.mesh_bvh = scenes.build_object_bvh(lo, hi)
+    for buf, data in ((m._meshObjectBuffer, mo), (m._vertexBuffer, sc.vertices), (m._indexBuffer, sc.indices),
+                      (m._normalBuffer, sc.normals), (m._meshObjectBVHBuffer, sc.mesh_bvh)):
+        buf.SetData(data)                                    # everything re-uploaded, as RebuildTrees does
+    m._frame = 0; m._currentSample = 0
+    m.OnRenderImage()
+    reused1, built1 = gpu_ctx.blas_cache_stats()
+    assert built1 - built0 == 1 and reused1 - reused0 == n - 1, (reused0, built0, reused1, built1)
+    o = pyoracle.Oracle(sc)
+    nodes, tri, root, _, _ = debug_build_blas(sc.mesh_objects, sc.vertices, sc.indices)   # a from-scratch build of the moved scene
+    o.set_blas(nodes, tri, root)
+    assert bits_equal(m._target.GetPixels(), o.render(mode=1, threads=4))
+    m.OnDisable()
+
+
 def test_resize_resets_accumulation_and_external_texture(gpu_ctx):
     sc = scenes.mixed_test_scene(64, 40)
     m = RayTraceMaster(gpu_ctx, sc)

@@ -142,7 +142,7 @@ void set_blas_leaf_max(int n) { g_leaf_max = std::min(std::max(n, 1), kLeafHardM
 int get_blas_leaf_max() { return g_leaf_max; }
 
 bool build_blas(const uint8_t* mesh_objects, int n_meshes, const float* vertices, int n_vertices, const int32_t* indices,
-                int n_indices, const float* normals, int n_normals, BlasResult& out, std::string& err) {
+                int n_indices, const float* normals, int n_normals, BlasResult& out, std::string& err, BlasCache* cache) {
   out = BlasResult();
   out.mesh_root.assign((size_t)n_meshes, kEmptyMeshRoot);
   out.mesh_first_tri.assign((size_t)n_meshes, 0);
@@ -158,18 +158,44 @@ bool build_blas(const uint8_t* mesh_objects, int n_meshes, const float* vertices
       B.err = "MeshObject " + std::to_string(m) + ": indices_offset/count outside _Indices";
       return;
     }
-    float ext = 0;
-    B.prims.reserve((size_t)(cnt / 3));
-    for (long i = off; i + 2 < off + cnt; i += 3) {
-      Prim p; p.slot = (int32_t)i;
-      for (int k = 0; k < 3; k++) { p.lo[k] = std::numeric_limits<float>::infinity(); p.hi[k] = -p.lo[k]; }
+    // validate the index slots; with a cache, hash what the BVH depends on in the same pass
+    uint64_t h1 = 0xcbf29ce484222325ull, h2 = 0x9e3779b97f4a7c15ull;
+    auto mix = [&](uint32_t w) {
+      h1 = (h1 ^ w) * 0x100000001b3ull;
+      h2 = (h2 ^ ((uint64_t)w * 0xff51afd7ed558ccdull)); h2 = (h2 << 27 | h2 >> 37) * 0xc4ceb9fe1a85ec53ull + 0x52dce729ull;
+    };
+    mix((uint32_t)g_leaf_max); mix((uint32_t)(cnt / 3));
+    for (int k = 0; k < 16; k++) mix(urt::f_bits(mo.localToWorldMatrix[k]));
+    for (long i = off; i + 2 < off + cnt; i += 3)
       for (int j = 0; j < 3; j++) {
         int32_t vi = indices[i + j];
         if (vi < 0 || vi >= n_vertices || (normals && vi >= n_normals)) {
           B.err = "_Indices[" + std::to_string(i + j) + "] = " + std::to_string(vi) + " is outside _Vertices/_Normals";
           return;
         }
-        const float* v = vertices + 3 * (size_t)vi;
+        if (cache) { const float* v = vertices + 3 * (size_t)vi; mix(urt::f_bits(v[0])); mix(urt::f_bits(v[1])); mix(urt::f_bits(v[2])); }
+      }
+    if (cache) {
+      std::lock_guard<std::mutex> g(cache->lock);
+      auto it = cache->map.find(h1);
+      if (it != cache->map.end() && it->second.check == h2) {
+        BlasCacheEntry& e = it->second;
+        e.last_use = cache->generation;
+        cache->hits++;
+        B.nodes = e.nodes;
+        B.tri_slot.resize(e.tri_rel.size());
+        for (size_t k = 0; k < e.tri_rel.size(); k++) B.tri_slot[k] = e.tri_rel[k] + (int32_t)off;
+        B.root = e.root; B.max_depth = e.max_depth;
+        return;
+      }
+    }
+    float ext = 0;
+    B.prims.reserve((size_t)(cnt / 3));
+    for (long i = off; i + 2 < off + cnt; i += 3) {
+      Prim p; p.slot = (int32_t)i;
+      for (int k = 0; k < 3; k++) { p.lo[k] = std::numeric_limits<float>::infinity(); p.hi[k] = -p.lo[k]; }
+      for (int j = 0; j < 3; j++) {
+        const float* v = vertices + 3 * (size_t)indices[i + j];
         urt::v3 w = urt::mul_m4(mo.localToWorldMatrix, v[0], v[1], v[2], 1.0f);
         const float wv[3] = {w.x, w.y, w.z};
         for (int k = 0; k < 3; k++) {
@@ -185,7 +211,18 @@ bool build_blas(const uint8_t* mesh_objects, int n_meshes, const float* vertices
     Box root;
     B.root = B.build(0, (int)B.prims.size(), 1, root);
     std::vector<Prim>().swap(B.prims);
+    if (cache) {
+      BlasCacheEntry e;
+      e.check = h2; e.nodes = B.nodes; e.root = B.root; e.max_depth = B.max_depth;
+      e.tri_rel.resize(B.tri_slot.size());
+      for (size_t k = 0; k < B.tri_slot.size(); k++) e.tri_rel[k] = B.tri_slot[k] - (int32_t)off;
+      std::lock_guard<std::mutex> g(cache->lock);
+      e.last_use = cache->generation;
+      cache->builds++;
+      cache->map[h1] = std::move(e);
+    }
   };
+  if (cache) { std::lock_guard<std::mutex> g(cache->lock); cache->generation++; }
   {
     unsigned hw = std::thread::hardware_concurrency();
     int n_threads = (int)std::min<size_t>(std::min<size_t>(hw ? hw : 1, 16), (size_t)std::max(1, n_meshes));
@@ -219,6 +256,10 @@ bool build_blas(const uint8_t* mesh_objects, int n_meshes, const float* vertices
     out.mesh_root[(size_t)m] = rebase(B.root);
     out.max_depth = std::max(out.max_depth, B.max_depth);
     B = Builder();
+  }
+  if (cache) {                       // keep only what this scene uses
+    std::lock_guard<std::mutex> g(cache->lock);
+    for (auto it = cache->map.begin(); it != cache->map.end();) { if (it->second.last_use != cache->generation) it = cache->map.erase(it); else ++it; }
   }
   // Renumber the interior nodes so that the first kTopOrderNodes indices are the TOP of the forest in breadth-first order
   // (all roots, then their children, ...): the phase-scheduled kernel keeps nodes [0, T) in LDS and walks them before a ray

@@ -71,6 +71,7 @@ struct urt_context {
   DevScene ds{};
   std::vector<void*> scene_allocs;
   int tlas_stack = 2, blas_stack = 2;
+  BlasCache blas_cache;                     // per-MeshObject BVHs of the previous scene (reused when a MeshObject is unchanged)
   int n_blas_nodes = 0;                     // interior nodes of the triangle-BVH forest (all meshes)
   unsigned int watchdog_steps = 1u << 16;
   float4* zero_sky = nullptr;
@@ -193,7 +194,7 @@ int prepare_scene(urt_context* ctx) {
     std::string err;
     if (!build_blas(bm->host.data(), n_meshes, bv ? (const float*)bv->host.data() : nullptr, bv ? bv->count : 0,
                     bi ? (const int32_t*)bi->host.data() : nullptr, bi ? bi->count : 0,
-                    bn ? (const float*)bn->host.data() : nullptr, bn ? bn->count : 0, blas, err))
+                    bn ? (const float*)bn->host.data() : nullptr, bn ? bn->count : 0, blas, err, &ctx->blas_cache))
       return fail(ctx, URT_ERR_SCENE, err);
     for (int m = 0; m < n_meshes; m++) {
       urt_MeshObject mo;
@@ -849,6 +850,14 @@ int urt_debug_build_blas(const void* mesh_objects, int n_meshes, const float* ve
   if (out_max_depth) *out_max_depth = g_debug_blas.max_depth;
   return URT_OK;
   URT_GUARD_END(nullptr)
+}
+
+int urt_debug_blas_cache_stats(urt_context* ctx, uint64_t* out_reused, uint64_t* out_built) {
+  if (!ctx) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  std::lock_guard<std::mutex> g(ctx->blas_cache.lock);
+  if (out_reused) *out_reused = ctx->blas_cache.hits;
+  if (out_built) *out_built = ctx->blas_cache.builds;
+  return URT_OK;
 }
 
 int urt_debug_get_blas(float* nodes, int32_t* tri_index, int32_t* mesh_root, int32_t* mesh_first_tri) {

@@ -61,6 +61,12 @@ class Context:
         self.check(self.lib.urt_get_counters(self._h, C.byref(c)))
         return c.as_dict()
 
+    def blas_cache_stats(self) -> tuple:
+        """(MeshObject BVHs reused, built) by this context's scene preparations so far."""
+        a, b = C.c_uint64(), C.c_uint64()
+        self.check(self.lib.urt_debug_blas_cache_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def reset_counters(self):
         self.check(self.lib.urt_reset_counters(self._h))
 
