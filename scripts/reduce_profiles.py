@@ -6,13 +6,21 @@ prefix = sys.argv[2] if len(sys.argv) > 2 else "r01_bench_c3"
 dst = "profiles"
 KERNEL = "k_sched<false"   # the timed trace kernel (counting replay is k_sched<true ...)
 
-stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
+def newest(pattern):
+    """one file per pass directory: gpurun merges new results next to older ones"""
+    by_dir = {}
+    for f in glob.glob(pattern, recursive=True):
+        d = f[len(src):].strip(os.sep).split(os.sep)[0]
+        if d not in by_dir or os.path.getmtime(f) > os.path.getmtime(by_dir[d]): by_dir[d] = f
+    return sorted(by_dir.values())
+
+stats = sorted(glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime, reverse=True)
 if stats:
     shutil.copy(stats[0], os.path.join(dst, f"{prefix}_kernel_stats.csv"))
     for r in csv.DictReader(open(stats[0])):
         if KERNEL in r["Name"]: print("kernel stats:", r["Name"][:60], "calls", r["Calls"], "avg ns", r["AverageNs"])
 pmc = {}
-for f in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+for f in newest(os.path.join(src, "pmc_*", "**", "*counter_collection.csv")):
     acc = {}
     for r in csv.DictReader(open(f)):
         if KERNEL not in r["Kernel_Name"]: continue
