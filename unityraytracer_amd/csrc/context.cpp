@@ -365,7 +365,7 @@ int do_dispatch(urt_context* ctx, int kernel, int gx, int gy, int gz, int first_
       bool shared = t > 0 || P.lds_mesh || P.lds_sphere;
       P.block_threads = ctx->opt_sched_block > 0 ? ctx->opt_sched_block : (shared ? 256 : 64);   // nothing to share: single waves
       P.top_nodes = t;
-      size_t groups = 20 / (size_t)(P.block_threads / 64);
+      size_t groups = std::max<size_t>(1, (size_t)(ctx->opt_waves_per_cu > 0 ? ctx->opt_waves_per_cu : 20) / (size_t)(P.block_threads / 64));   // workgroups per CU that must fit
       const size_t budget = 156 * 1024;                          // (a little of the 160 KiB goes to allocation granules)
       while (P.top_nodes > 0 && sched_lds_bytes(S, P) * groups > budget) P.top_nodes /= 2;
       if (sched_lds_bytes(S, P) * groups > budget) { P.lds_mesh = 0; P.lds_sphere = 0; }
