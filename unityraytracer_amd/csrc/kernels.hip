@@ -10,11 +10,16 @@
 //    with a per-lane stack that lives in LDS ([entry][lane] layout: conflict-free, no scratch);
 //  * the reference carries a 68-byte RayHit with the material through traversal (RS:36-41); here the
 //    traversal carries (t, kind, id, u, v) and normals/material are fetched once per closest hit;
-//  * the reference is one thread per pixel for all bounces; the default mode here is a wavefront
-//    pipeline: one kernel launch per bounce over a COMPACTED queue of live paths (wave64 ballot +
-//    prefix popcount + one atomic per wave), so lanes whose paths ended on the sky do not idle;
-//  * pixel -> lane mapping is one 8x8 tile per wave (the reference's group shape) with an XCD-aware
-//    block order so that one XCD's L2 serves one contiguous band of the image.
+//  * the reference is one thread per pixel for all bounces; the default kernel here (k_sched, kernel_mode 3) keeps a
+//    fixed grid of waves resident for the whole frame: a lane whose path has ended takes a new pixel from the frame's
+//    sharded work counter (wave64 ballot + prefix popcount + ONE atomic per refill), and the lanes of a wave are
+//    scheduled by phase (object-level walk / triangle-BVH loop / shading) so that the long loops run for the lanes
+//    that need them;
+//  * the hot, small tables live in LDS next to the stacks: the breadth-first top of the triangle-BVH forest, the
+//    object-level heaps, MeshObject roots and sphere centres/radii (k_sched prologue);
+//  * the other kernel modes (0 one thread per pixel, 1 one launch per bounce over compacted queues, 2 persistent waves
+//    without phase scheduling, 4 a path pool in LDS) share every device function with the default one and exist as
+//    measured alternatives and cross-checks.
 // Arithmetic is the normative float32 of include/urt_math.h, compiled with -ffp-contract=off; results
 // are bit-identical to the scalar restatement in oracle/ (tests/test_gpu_parity.py).
 #include <hip/hip_runtime.h>
@@ -742,12 +747,15 @@ __device__ __forceinline__ bool trace_front(const DevScene& S, bool fresh, v3 o,
 // a small state machine
 //     DEAD -> FRONT (ground plane + object-level heap walk) -> BLAS (triangle BVH of one MeshObject)
 //          -> RESUME (rest of the heap walk, spheres) -> SHADE -> FRONT (next bounce / ray) | DEAD
-// and each trip round the wave loop the 64 lanes vote (ballot) on ONE phase to run.  Cheap phases (SHADE,
-// FRONT, refill) run until at least `blas_min` lanes are parked in BLAS, then the traversal loop runs with
-// that many lanes; it hands control back when fewer than `blas_exit` lanes are still traversing (their
-// stack lives in LDS and the node cursor in registers, so they resume later).  Per-pixel arithmetic and the
-// order of its operations are exactly those of modes 0-2 (same device functions) — only WHEN a lane
-// executes them changes, so pixels are bit-identical.
+// and each trip round the wave loop the 64 lanes vote (ballot) on ONE phase to run.  Cheap phases (SHADE from
+// `shade_min` lanes, FRONT, refill from `refill_min` dead lanes) run until at least `blas_min` lanes are parked in
+// BLAS, then the traversal loop runs with that many lanes; it hands control back when fewer than `blas_exit` lanes are
+// still traversing (their stack lives in LDS and the node cursor in registers, so they resume later).
+// A workgroup is 4 such waves that share nothing but read-only LDS copies made in the prologue: the breadth-first top
+// of the BVH forest (a ray entering a mesh walks it on its own, at LDS latency, before it joins the wave-wide loop —
+// inside FRONT when TOPF, i.e. for multi-mesh scenes, else at the start of the BLAS phase) and the small object-level
+// tables.  Per-pixel arithmetic and the order of its operations are exactly those of modes 0-2 (same device
+// functions) — only WHEN and WHERE a lane executes them changes, so pixels are bit-identical.
 // ---------------------------------------------------------------------------------------------------
 enum : int { ST_DEAD = 0, ST_FRONT = 1, ST_RESUME = 2, ST_BLAS = 3, ST_SHADE = 4 };
 static constexpr unsigned int kWatchdogIters = 1u << 24;    // scheduler trips per wave (a frame needs ~1e3-1e5)
