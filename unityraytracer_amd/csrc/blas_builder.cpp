@@ -47,9 +47,13 @@ struct Box {
 constexpr int kBins = 16;
 int g_leaf_max = 4;              // SAH leaves (tunable: URT_BLAS_LEAF_MAX / urt_set_option "blas_leaf_max")
 constexpr int kLeafHardMax = 8;  // encoding limit (3 bits)
+constexpr int kForkMinPrims = 8192;   // subtrees at least this big may get a thread of their own
 
 struct Builder {
-  std::vector<Prim> prims;
+  std::vector<Prim> prims;           // owned by the MeshObject's root builder ...
+  Prim* P = nullptr;                 // ... and shared (disjoint index ranges) with the builders of its big subtrees
+  int fork_levels = 0;               // levels below which big subtrees may still be built on their own thread ...
+  std::atomic<int>* spare = nullptr; // ... when one of the build's threads is idle (shared counter)
   // output of ONE mesh, in mesh-local numbering (node indices and leaf-order triangle slots start at 0): meshes are built
   // independently (in parallel) and concatenated afterwards
   std::vector<float> nodes;
@@ -61,9 +65,27 @@ struct Builder {
 
   int32_t make_leaf(int lo, int hi) {
     uint32_t first = (uint32_t)tri_slot.size();
-    for (int q = lo; q < hi; q++) tri_slot.push_back(prims[q].slot);
+    for (int q = lo; q < hi; q++) tri_slot.push_back(P[q].slot);
     uint32_t code = (first << 3) | (uint32_t)(hi - lo - 1);
     return (int32_t)~code;
+  }
+
+  // append a subtree built elsewhere (its own local numbering) and return its root's code in THIS builder's numbering
+  int32_t append(const Builder& sub, int32_t code) {
+    int32_t node_base = (int32_t)(nodes.size() / kBlasNodeFloats);
+    uint32_t tri_base = (uint32_t)tri_slot.size();
+    auto rebase = [&](int32_t c) -> int32_t {
+      if (c >= 0) return c + node_base;
+      uint32_t u = ~(uint32_t)c;
+      return (int32_t)~((((u >> 3) + tri_base) << 3) | (u & 7u));
+    };
+    size_t at = nodes.size();
+    nodes.insert(nodes.end(), sub.nodes.begin(), sub.nodes.end());
+    for (size_t k = at; k < nodes.size(); k += kBlasNodeFloats)
+      for (int c = 0; c < 2; c++) nodes[k + 12 + c] = urt::bits_f((uint32_t)rebase((int32_t)urt::f_bits(nodes[k + 12 + c])));
+    tri_slot.insert(tri_slot.end(), sub.tri_slot.begin(), sub.tri_slot.end());
+    max_depth = std::max(max_depth, sub.max_depth);
+    return rebase(code);
   }
 
   // returns the child code for prims[lo,hi) and writes its (padded) box
@@ -72,7 +94,7 @@ struct Builder {
     int n = hi - lo;
     box.reset();
     Box cb; cb.reset();
-    for (int q = lo; q < hi; q++) { box.grow(prims[q].lo, prims[q].hi); cb.grow(prims[q].c, prims[q].c); }
+    for (int q = lo; q < hi; q++) { box.grow(P[q].lo, P[q].hi); cb.grow(P[q].c, P[q].c); }
     if (n <= g_leaf_max) return make_leaf(lo, hi);
 
     // binned SAH over the three axes
@@ -86,9 +108,9 @@ struct Builder {
       for (auto& b : bb) b.reset();
       float scale = (float)kBins / ext;
       for (int q = lo; q < hi; q++) {
-        int b = (int)((prims[q].c[ax] - cb.lo[ax]) * scale);
+        int b = (int)((P[q].c[ax] - cb.lo[ax]) * scale);
         b = std::min(std::max(b, 0), kBins - 1);
-        cnt[b]++; bb[b].grow(prims[q].lo, prims[q].hi);
+        cnt[b]++; bb[b].grow(P[q].lo, P[q].hi);
       }
       float right_area[kBins]; int right_cnt[kBins];
       Box acc; acc.reset(); int c = 0;
@@ -107,12 +129,12 @@ struct Builder {
       float scale = (float)kBins / ext;
       float clo = cb.lo[best_axis];
       int ax = best_axis, bin = best_bin;
-      auto it = std::partition(prims.begin() + lo, prims.begin() + hi, [=](const Prim& p) {
+      Prim* it = std::partition(P + lo, P + hi, [=](const Prim& p) {
         int b = (int)((p.c[ax] - clo) * scale);
         b = std::min(std::max(b, 0), kBins - 1);
         return b <= bin;
       });
-      mid = (int)(it - prims.begin());
+      mid = (int)(it - P);
     } else {
       mid = lo;   // all centroids coincide
     }
@@ -123,8 +145,27 @@ struct Builder {
     int32_t me = (int32_t)(nodes.size() / kBlasNodeFloats);
     nodes.resize(nodes.size() + kBlasNodeFloats, 0.0f);
     Box b0, b1;
-    int32_t c0 = build(lo, mid, depth + 1, b0);
-    int32_t c1 = build(mid, hi, depth + 1, b1);
+    int32_t c0, c1;
+    bool fork = false;
+    if (fork_levels > 0 && n >= kForkMinPrims && spare) {
+      if (spare->fetch_sub(1) > 0) fork = true; else spare->fetch_add(1);
+    }
+    if (fork) {
+      // big node near the root: its two subtrees are built concurrently in builders of their own and appended in the order
+      // a sequential build would have produced them (node order and leaf order are unchanged)
+      Builder L, R;
+      L.P = R.P = P; L.pad = R.pad = pad; L.fork_levels = R.fork_levels = fork_levels - 1; L.spare = R.spare = spare;
+      int32_t l0 = 0, l1 = 0;
+      std::thread t([&]() { l0 = L.build(lo, mid, depth + 1, b0); });
+      l1 = R.build(mid, hi, depth + 1, b1);
+      t.join();
+      spare->fetch_add(1);
+      c0 = append(L, l0);
+      c1 = append(R, l1);
+    } else {
+      c0 = build(lo, mid, depth + 1, b0);
+      c1 = build(mid, hi, depth + 1, b1);
+    }
     float* nd = nodes.data() + (size_t)me * kBlasNodeFloats;
     for (int k = 0; k < 3; k++) {
       nd[k] = b0.lo[k] - pad; nd[3 + k] = b0.hi[k] + pad;
@@ -149,6 +190,12 @@ bool build_blas(const uint8_t* mesh_objects, int n_meshes, const float* vertices
   // one independent build per MeshObject, spread over the host's cores; concatenated in MeshObject order afterwards, so the
   // result does not depend on the number of threads
   std::vector<Builder> builds((size_t)n_meshes);
+  int n_threads_total = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+  if (n_indices < 30000) n_threads_total = 1;                       // small scenes: not worth starting threads
+  if (const char* e = std::getenv("URT_BLAS_THREADS")) { int v = std::atoi(e); if (v >= 1) n_threads_total = std::min(v, 64); }   // tests
+  // threads that are not busy with a MeshObject of their own go to the big subtrees of the ones still being built
+  const int fork_levels = n_threads_total > 1 ? 4 : 0;
+  std::atomic<int> spare(0);
   auto build_one = [&](int m) {
     Builder& B = builds[(size_t)m];
     urt_MeshObject mo;
@@ -209,6 +256,8 @@ bool build_blas(const uint8_t* mesh_objects, int n_meshes, const float* vertices
     if (B.prims.empty()) return;
     B.pad = ext * 1.52587890625e-5f + 1e-30f;
     Box root;
+    B.P = B.prims.data();
+    B.fork_levels = fork_levels; B.spare = &spare;
     B.root = B.build(0, (int)B.prims.size(), 1, root);
     std::vector<Prim>().swap(B.prims);
     if (cache) {
@@ -224,12 +273,10 @@ bool build_blas(const uint8_t* mesh_objects, int n_meshes, const float* vertices
   };
   if (cache) { std::lock_guard<std::mutex> g(cache->lock); cache->generation++; }
   {
-    unsigned hw = std::thread::hardware_concurrency();
-    int n_threads = (int)std::min<size_t>(std::min<size_t>(hw ? hw : 1, 16), (size_t)std::max(1, n_meshes));
-    if (n_indices < 30000) n_threads = 1;                       // small scenes: not worth starting threads
-    if (const char* e = std::getenv("URT_BLAS_THREADS")) { int v = std::atoi(e); if (v >= 1) n_threads = std::min(v, 64); }   // tests
+    int n_threads = std::min(n_threads_total, std::max(1, n_meshes));
     std::atomic<int> next_mesh(0);
-    auto worker = [&]() { for (int m; (m = next_mesh.fetch_add(1)) < n_meshes;) build_one(m); };
+    spare.store(n_threads_total - n_threads);                  // threads beyond one per MeshObject worker
+    auto worker = [&]() { for (int m; (m = next_mesh.fetch_add(1)) < n_meshes;) build_one(m); spare.fetch_add(1); };   // an idle worker's slot is up for grabs
     std::vector<std::thread> pool;
     for (int t = 1; t < n_threads; t++) pool.emplace_back(worker);
     worker();
