@@ -159,6 +159,21 @@ def test_multi_ray_multi_frame_accumulation(gpu_ctx):
         assert_same(conv, conv_ref, f"3-frame running mean, mode {mode}")
 
 
+def test_long_progressive_accumulation(gpu_ctx):
+    """200 frames of the running mean (AS:9,39-41 with _Sample = 0..199, per-frame _PixelOffset/_Seed): the converged image
+    still equals the oracle's bit for bit — the blend is evaluated in the same order on both sides, so nothing drifts."""
+    sc = scenes.mixed_test_scene(64, 40)
+    o = oracle_for(sc)
+    conv_ref = np.zeros((40, 64, 4), np.float32)
+    for f in range(200):
+        ox, oy, seed = scenes.frame_uniforms(f)
+        o.set_frame((ox, oy), seed)
+        conv_ref = pyoracle.accumulate(o.render(mode=1, threads=8), conv_ref, f)
+    _, conv, c = render_gpu(gpu_ctx, sc, 3, frames=200)
+    assert_same(conv, conv_ref, "200-frame running mean")
+    assert np.isfinite(conv).all() and c["watchdog_trips"] == 0
+
+
 def test_strips_union_equals_full_frame(gpu_ctx):
     """dispatch_rows(r, N) for r = 0..N-1 writes exactly the pixels of one full dispatch (global ids)."""
     sc = scenes.mixed_test_scene(120, 100)
