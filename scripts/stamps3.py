@@ -6,8 +6,11 @@ ctx = Context(0)
 lib = _lib.load()
 lib.urt_debug_read_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 import itertools
+cfg = sys.argv[1] if len(sys.argv) > 1 else None
 for (w, h, b), wpc in itertools.product(((1920, 1080, 8),), (20,)):
-    sc = scenes.config3(w, h); sc.num_bounces = b
+    sc = scenes.CONFIGS[cfg]() if cfg else scenes.config3(w, h)
+    if not cfg: sc.num_bounces = b
+    w, h, b = sc.width, sc.height, sc.num_bounces
     ctx.set_option("kernel_mode", 3); ctx.set_option("waves_per_cu", wpc)
     print(f"--- waves/CU {wpc}")
     m = RayTraceMaster(ctx, sc)

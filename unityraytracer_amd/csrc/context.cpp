@@ -203,6 +203,18 @@ int prepare_scene(urt_context* ctx) {
     }
     const float4* p;
     if ((rc = upload(ctx, blas.mesh_root, &p))) return rc; S.mesh_root = (const int32_t*)p;
+    {   // single-leaf MeshObjects: where their triangles sit in the LDS copy (kernels.hip k_sched prologue)
+      std::vector<int32_t> small_first((size_t)n_meshes, -1);
+      int n_small = 0;
+      for (int m = 0; m < n_meshes; m++) {
+        int32_t r = blas.mesh_root[(size_t)m];
+        if (r < 0 && r != (int32_t)0x80000000) { small_first[(size_t)m] = n_small; n_small += (int)((~(uint32_t)r) & 7u) + 1; }
+      }
+      if (n_small > 0 && n_small <= 64) {
+        if ((rc = upload(ctx, small_first, &p))) return rc;
+        S.mesh_small_first = (const int32_t*)p; S.n_small = n_small;
+      }
+    }
     if ((rc = upload(ctx, blas.nodes, &p))) return rc; S.blas_nodes = p;
     if ((rc = upload(ctx, blas.tri_verts, &p))) return rc; S.tri_verts = p;
     if ((rc = upload(ctx, blas.tri_norms, &p))) return rc; S.tri_norms = p;
@@ -361,6 +373,7 @@ int do_dispatch(urt_context* ctx, int kernel, int gx, int gy, int gz, int first_
       int t = std::min(std::min(ctx->opt_top_nodes, (int)kTopOrderNodes), ctx->n_blas_nodes);
       // small object-level tables (<= 256 entries) also live in LDS: their walk is a chain of dependent fetches
       P.lds_mesh = ctx->opt_lds_tlas && S.n_mesh_tlas > 0 && S.n_mesh_tlas <= 256 && S.n_meshes <= 256;
+      P.lds_small = P.lds_mesh && S.n_small > 0;
       P.lds_sphere = ctx->opt_lds_tlas && S.n_sphere_tlas > 0 && S.n_sphere_tlas <= 256 && S.n_spheres <= 256;
       bool shared = t > 0 || P.lds_mesh || P.lds_sphere;
       P.block_threads = ctx->opt_sched_block > 0 ? ctx->opt_sched_block : (shared ? 256 : 64);   // nothing to share: single waves
@@ -368,7 +381,7 @@ int do_dispatch(urt_context* ctx, int kernel, int gx, int gy, int gz, int first_
       size_t groups = std::max<size_t>(1, (size_t)(ctx->opt_waves_per_cu > 0 ? ctx->opt_waves_per_cu : 20) / (size_t)(P.block_threads / 64));   // workgroups per CU that must fit
       const size_t budget = 156 * 1024;                          // (a little of the 160 KiB goes to allocation granules)
       while (P.top_nodes > 0 && sched_lds_bytes(S, P) * groups > budget) P.top_nodes /= 2;
-      if (sched_lds_bytes(S, P) * groups > budget) { P.lds_mesh = 0; P.lds_sphere = 0; }
+      if (sched_lds_bytes(S, P) * groups > budget) { P.lds_mesh = 0; P.lds_sphere = 0; P.lds_small = 0; }
     }
     int waves_per_block = P.block_threads / 64;
     long want = ((long)P.tiles_x * P.n_strips + waves_per_block - 1) / waves_per_block;

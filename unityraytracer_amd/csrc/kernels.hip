@@ -105,10 +105,20 @@ __device__ __forceinline__ void test_triangle(float4 r0, float4 r1, float4 r2, i
   if (closer) { best.t = t; best.kind = 3; best.id = slot_in_leaf_order; best.u = u; best.v = v; best_i = islot; }
 }
 
+// `lds_first` >= 0: the leaf's records are read from `lds_tris` (an LDS copy) starting at triangle lds_first instead of
+// from the global array; the leaf-order slot reported for a hit is the global one either way.
 template <bool COUNT>
-__device__ __forceinline__ void test_leaf(const DevScene& S, int32_t leaf, v3 o, v3 d, HitRec& best, int& best_i, LocalCounters& lc) {
+__device__ __forceinline__ void test_leaf(const DevScene& S, int32_t leaf, v3 o, v3 d, HitRec& best, int& best_i, LocalCounters& lc,
+                                          const float4* lds_tris = nullptr, int lds_first = -1) {
   uint32_t code = ~(uint32_t)leaf;
   uint32_t first = code >> 3, cnt = (code & 7u) + 1u;
+  if (lds_first >= 0) {
+    for (uint32_t k = 0; k < cnt; k++) {
+      const float4* t = lds_tris + 3 * ((uint32_t)lds_first + k);
+      test_triangle<COUNT>(t[0], t[1], t[2], (int)(first + k), o, d, best, best_i, lc);
+    }
+    return;
+  }
   // two triangles per round: both records are requested before either is tested, so a leaf of 4 costs two memory
   // round trips on the dependent chain instead of four
   for (uint32_t k = 0; k < cnt; k += 2) {
@@ -666,6 +676,8 @@ struct FrontLds {
   const int32_t* mesh_root = nullptr;    // [n_meshes]
   const float4* sphere_tlas = nullptr;   // [2 * n_sphere_tlas]
   const float4* sphere_pr = nullptr;     // [n_spheres]
+  const float4* small_tris = nullptr;    // [3 * n_small] triangle records of the single-leaf MeshObjects
+  const int32_t* small_first = nullptr;  // [n_meshes] first triangle of MeshObject m in small_tris, or -1
 };
 
 template <bool COUNT, bool TOPF = false>
@@ -701,12 +713,13 @@ __device__ __forceinline__ bool trace_front(const DevScene& S, bool fresh, v3 o,
       if (L.mesh_root) root = L.mesh_root[index]; else root = S.mesh_root[index];
       if (root < 0 && root != kBlasDone) {               // a mesh of <= 8 triangles is one leaf: test it here, no phase switch
         int bi_local = -1;
-        test_leaf<COUNT>(S, root, o, d, best, bi_local, lc);
+        if (L.small_tris) test_leaf<COUNT>(S, root, o, d, best, bi_local, lc, L.small_tris, L.small_first[index]);
+        else test_leaf<COUNT>(S, root, o, d, best, bi_local, lc);
       } else if (root != kEmptyMeshRoot) {
         if (TOPF) {
           int sp = 0;
           if (root < top_nodes) {
-            BlasRay R = blas_ray(o, d);
+            BlasRay R = blas_ray(o, d);    // recomputed per MeshObject entered: keeping it live across the heap walk costs more (spills)
             do root = blas_node_step_top<COUNT>(top, root, R, best.t, bl, sp, lc); while (root >= 0 && root < top_nodes);
           }
           *sp_out = sp;
@@ -779,6 +792,19 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
     L.mesh_tlas = lds4 + at; at += 2 * S.n_mesh_tlas;
     for (int i = threadIdx.x; i < S.n_meshes; i += blockDim.x) ((int32_t*)(lds4 + at))[i] = S.mesh_root[i];
     L.mesh_root = (const int32_t*)(lds4 + at); at += (S.n_meshes + 3) / 4;
+    if (P.lds_small) {                                          // triangle records of the single-leaf MeshObjects (quads, planes)
+      for (int i = threadIdx.x; i < S.n_meshes; i += blockDim.x) ((int32_t*)(lds4 + at))[i] = S.mesh_small_first[i];
+      L.small_first = (const int32_t*)(lds4 + at); at += (S.n_meshes + 3) / 4;
+      for (int m = threadIdx.x; m < S.n_meshes; m += blockDim.x) {
+        int sf = S.mesh_small_first[m];
+        if (sf >= 0) {
+          uint32_t code = ~(uint32_t)S.mesh_root[m];
+          uint32_t first = code >> 3, cnt = (code & 7u) + 1u;
+          for (uint32_t q = 0; q < 3 * cnt; q++) lds4[at + 3 * sf + q] = S.tri_verts[3 * (size_t)first + q];
+        }
+      }
+      L.small_tris = lds4 + at; at += 3 * S.n_small;
+    }
   }
   if (P.lds_sphere) {                                           // object-level sphere heap + sphere positions/radii
     for (int i = threadIdx.x; i < 2 * S.n_sphere_tlas; i += blockDim.x) lds4[at + i] = S.sphere_tlas[i];
@@ -1396,6 +1422,7 @@ hipError_t launch_persist(const DevScene& S, const FrameParams& P, float4* resul
 size_t sched_lds_bytes(const DevScene& S, const FrameParams& P) {
   size_t f4 = (size_t)P.top_nodes * 4;
   if (P.lds_mesh) f4 += 2 * (size_t)S.n_mesh_tlas + ((size_t)S.n_meshes + 3) / 4;
+  if (P.lds_small) f4 += ((size_t)S.n_meshes + 3) / 4 + 3 * (size_t)S.n_small;
   if (P.lds_sphere) f4 += 2 * (size_t)S.n_sphere_tlas + (size_t)S.n_spheres;
   return f4 * 16 + (size_t)(P.tlas_stack + P.blas_stack) * 64 * (size_t)(P.block_threads / 64) * sizeof(int);
 }

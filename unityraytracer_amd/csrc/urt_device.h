@@ -27,6 +27,9 @@ struct DevScene {
   const float4* materials;
   // mesh objects (RS:43-49)
   const int32_t* mesh_root;  int n_meshes;
+  // MeshObjects that are a single BVH leaf (<= 8 triangles: quads, planes): position of their triangle records in the LDS copy
+  // the phase scheduler keeps of them (in triangles), or -1; n_small = triangles in that copy (0 = none)
+  const int32_t* mesh_small_first; int n_small;
   // triangle BVH over world-space triangles, all meshes in one pool
   const float4* blas_nodes;  // 4 x float4 per node
   const float4* tri_verts;   // [3k] v0.xyz, index slot i (int bits)  [3k+1] e1.xyz, mesh id (int bits)  [3k+2] e2.xyz, 0
@@ -58,6 +61,7 @@ struct FrameParams {
   int shade_min;            // mode 3: SHADE lanes that make the phase run ahead of FRONT (1..64)
   int blas_exit;            // mode 3: the traversal phase yields when fewer lanes than this are still traversing (1..64)
   int top_nodes;            // mode 3: triangle-BVH nodes [0, top_nodes) are copied to LDS (breadth-first top of the forest); 0 = none
+  int lds_small;            // mode 3: triangle records of the single-leaf MeshObjects in LDS (needs lds_mesh) (0/1)
   int lds_mesh, lds_sphere; // mode 3: keep the object-level mesh heap + roots / sphere heap + spheres in LDS (0/1)
   int pool_inloop;          // mode 4: idle lanes that trigger a re-feed of the traversal phase from the waiting rays (1..64)
   int pool_other_min;       // mode 4: lanes of FRONT / SHADE work that make those phases worth a trip while rays queue for the BVH
