@@ -155,7 +155,8 @@ typedef struct urt_counters {
  *                  walked), "lds_tlas" (0/1: small object-level tables in LDS),
  *          mode 4: "pool_k" (1..4), "pool_refill", "pool_blas_min" (1..256), "pool_blas_exit", "pool_inloop",
  *                  "pool_other_min" (1..64),
- *          "blas_leaf_max" (1..8: triangles per BVH leaf; rebuilds the BVH)
+ *          "blas_leaf_max" (1..8: triangles per BVH leaf; rebuilds the BVH),
+ *          "stack_pad" (0..96: test hook, unused extra entries per traversal stack -> the > 64 KiB LDS launch path)
  *          — tuning knobs; they change speed only, never pixels. */
 URT_API int urt_set_option(urt_context* ctx, const char* name, int value);
 URT_API int urt_get_counters(urt_context* ctx, urt_counters* out);   /* synchronises */

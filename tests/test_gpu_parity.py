@@ -130,6 +130,21 @@ def test_many_meshes_beyond_the_lds_tables(gpu_ctx):
         gpu_ctx.set_option("top_nodes", 64); gpu_ctx.set_option("top_front", -1)
 
 
+def test_deep_stacks_use_the_large_lds_launch_path(gpu_ctx):
+    """A very deep BVH needs more than 64 KiB of LDS per 4-wave workgroup: the launch then raises the kernel's dynamic-LDS
+    limit and fewer workgroups fit a CU.  `stack_pad` inflates the stacks of a normal scene to get there."""
+    sc = scenes.mixed_test_scene(160, 96, blob=(40, 31))
+    ref = oracle_for(sc).render(mode=1, threads=8)
+    try:
+        for pad, mode in ((48, 3), (96, 3)):
+            gpu_ctx.set_option("stack_pad", pad)
+            gpu, _, gc = render_gpu(gpu_ctx, sc, mode)
+            assert_same(gpu, ref, f"stack_pad {pad}, mode {mode}")
+            assert gc["watchdog_trips"] == 0
+    finally:
+        gpu_ctx.set_option("stack_pad", 0)
+
+
 @pytest.mark.parametrize("k", [1, 2, 3, 4])
 def test_path_pool_sizes_bit_exact(gpu_ctx, k):
     sc = scenes.mixed_test_scene(200, 120)

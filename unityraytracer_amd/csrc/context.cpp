@@ -93,6 +93,7 @@ struct urt_context {
   int opt_block_threads = 64, opt_xcd_run = 1, opt_refill_min = 32, opt_waves_per_cu = 0 /* auto */, opt_blas_min = 28, opt_blas_exit = 6;
   int opt_pool_k = 2, opt_pool_refill = 32, opt_pool_blas_min = 48, opt_pool_blas_exit = 8, opt_pool_inloop = 16, opt_pool_other_min = 24;   // kernel_mode 4
   int opt_sched_block = 0;                  // kernel_mode 3: threads per workgroup (64 or 256; 0 = 256 when there is a BVH top to share)
+  int opt_stack_pad = 0;                    // test hook: extra (unused) entries per traversal stack, to reach the > 64 KiB LDS launch path
   int opt_shade_min = 32;                   // kernel_mode 3
   int opt_tile_order = 0;                   // persistent modes: order in which the frame's tiles are handed out
   int opt_lds_tlas = 1;                     // kernel_mode 3: object-level heaps, roots and spheres in LDS when small
@@ -335,7 +336,7 @@ int do_dispatch(urt_context* ctx, int kernel, int gx, int gy, int gz, int first_
   int group_rows = (P.region_h + 7) / 8;
   P.first_group_row = first_row; P.row_stride = row_stride;
   P.n_strips = first_row < group_rows ? (group_rows - first_row + row_stride - 1) / row_stride : 0;
-  P.tlas_stack = ctx->tlas_stack; P.blas_stack = ctx->blas_stack; P.watchdog_steps = ctx->watchdog_steps;
+  P.tlas_stack = ctx->tlas_stack; P.blas_stack = ctx->blas_stack + ctx->opt_stack_pad; P.watchdog_steps = ctx->watchdog_steps;
   P.block_threads = ctx->opt_block_threads; P.xcd_run = ctx->opt_xcd_run; P.tile_order = ctx->opt_tile_order; P.refill_min = ctx->opt_refill_min; P.blas_min = ctx->opt_blas_min; P.blas_exit = ctx->opt_blas_exit; P.shade_min = ctx->opt_shade_min;
   if (P.n_strips == 0 || P.tiles_x == 0) return URT_OK;
   if ((uint64_t)P.tiles_x * (uint64_t)P.n_strips * 64u >= 0xffffffffull)
@@ -768,6 +769,9 @@ int urt_set_option(urt_context* ctx, const char* name, int value) {
   } else if (std::strcmp(name, "sched_block") == 0) {
     if (value != 0 && value != 64 && value != 256) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "sched_block must be 0 (auto), 64 or 256");
     ctx->opt_sched_block = value;
+  } else if (std::strcmp(name, "stack_pad") == 0) {
+    if (value < 0 || value > 96) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "stack_pad must be in [0, 96]");
+    ctx->opt_stack_pad = value;
   } else if (std::strcmp(name, "shade_min") == 0) {
     if (value < 1 || value > 64) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "shade_min must be in [1, 64]");
     ctx->opt_shade_min = value;
