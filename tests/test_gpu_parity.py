@@ -136,7 +136,7 @@ def test_deep_stacks_use_the_large_lds_launch_path(gpu_ctx):
     sc = scenes.mixed_test_scene(160, 96, blob=(40, 31))
     ref = oracle_for(sc).render(mode=1, threads=8)
     try:
-        for pad, mode in ((48, 3), (96, 3)):
+        for pad, mode in ((48, 3), (96, 3), (96, 2), (96, 1), (96, 0)):
             gpu_ctx.set_option("stack_pad", pad)
             gpu, _, gc = render_gpu(gpu_ctx, sc, mode)
             assert_same(gpu, ref, f"stack_pad {pad}, mode {mode}")

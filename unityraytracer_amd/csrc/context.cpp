@@ -257,8 +257,8 @@ int prepare_scene(urt_context* ctx) {
   // a ray with NaN components passes every slab test and walks the whole tree once: (nodes + leaves) trips per lane, and the
   // majority vote can make a lane wait a trip for every trip it runs; 8x that is a bound no correct traversal reaches
   ctx->watchdog_steps = (unsigned int)std::min<size_t>(0x7fffffffu, 8 * (blas.nodes.size() / kBlasNodeFloats + blas.tri_slot.size()) + 4096);
-  if ((size_t)(ctx->tlas_stack + ctx->blas_stack) * 64 * 4 * sizeof(int) > 64 * 1024)   // at the largest workgroup (4 waves)
-    return fail(ctx, URT_ERR_SCENE, "traversal stacks exceed the 64 KiB LDS budget per workgroup");
+  if ((size_t)(ctx->tlas_stack + ctx->blas_stack) * 64 * 4 * sizeof(int) > 150 * 1024)   // 4-wave workgroup; a CU has 160 KiB
+    return fail(ctx, URT_ERR_SCENE, "traversal stacks exceed the LDS of a compute unit");
   ctx->scene_dirty = false;
   return URT_OK;
 }

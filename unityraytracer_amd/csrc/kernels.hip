@@ -1378,10 +1378,19 @@ static inline size_t stack_lds_bytes(const FrameParams& P) {
   return (size_t)(P.tlas_stack + P.blas_stack) * 64 * (size_t)(P.block_threads / 64) * sizeof(int);
 }
 
+// dynamic LDS above the default 64 KiB per workgroup (very deep BVHs): the kernel's limit has to be raised first
+template <typename K>
+static hipError_t allow_lds(K kernel, size_t lds) {
+  if (lds <= 64 * 1024) return hipSuccess;
+  return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
 hipError_t launch_mega(const DevScene& S, const FrameParams& P, float4* result, DevCounters* ctr, bool count, hipStream_t st) {
   int nb = blocks_for_tiles(P);
   if (nb == 0) return hipSuccess;
   size_t lds = stack_lds_bytes(P);
+  hipError_t ea = count ? allow_lds(k_mega<true>, lds) : allow_lds(k_mega<false>, lds);
+  if (ea != hipSuccess) return ea;
   if (count) hipLaunchKernelGGL(k_mega<true>, dim3(nb), dim3(P.block_threads), lds, st, S, P, result, ctr);
   else hipLaunchKernelGGL(k_mega<false>, dim3(nb), dim3(P.block_threads), lds, st, S, P, result, ctr);
   return hipGetLastError();
@@ -1394,6 +1403,8 @@ hipError_t launch_wavefront(const DevScene& S, const FrameParams& P, const PathQ
   size_t lds = stack_lds_bytes(P);
   size_t n_counts = (size_t)P.num_rays * (P.num_bounces + 1);
   hipError_t e = hipMemsetAsync(Q.counts, 0, n_counts * sizeof(unsigned int), st);
+  if (e != hipSuccess) return e;
+  e = count ? allow_lds(k_bounce<true>, lds) : allow_lds(k_bounce<false>, lds);
   if (e != hipSuccess) return e;
   size_t npix = (size_t)P.region_w * 8 * P.n_strips;
   int bt = P.block_threads;
@@ -1414,6 +1425,8 @@ hipError_t launch_persist(const DevScene& S, const FrameParams& P, float4* resul
   hipError_t e = hipMemsetAsync(next, 0, kWorkShards * 32 * sizeof(unsigned int), st);
   if (e != hipSuccess) return e;
   size_t lds = stack_lds_bytes(P);
+  e = count ? allow_lds(k_persist<true>, lds) : allow_lds(k_persist<false>, lds);
+  if (e != hipSuccess) return e;
   if (count) hipLaunchKernelGGL(k_persist<true>, dim3(n_blocks), dim3(P.block_threads), lds, st, S, P, result, ctr, next);
   else hipLaunchKernelGGL(k_persist<false>, dim3(n_blocks), dim3(P.block_threads), lds, st, S, P, result, ctr, next);
   return hipGetLastError();
