@@ -58,11 +58,9 @@ def frame_uniforms(frame: int, seed: int = 0x5EED):
     fixture (0.5, 0.5, 0.5); later frames come from splitmix64(seed) — three values per frame."""
     if frame == 0:
         return 0.5, 0.5, 0.5
-    rng = SplitMix64(seed)
-    v = (0.0, 0.0, 0.0)
-    for _ in range(frame):
-        v = (rng.value(), rng.value(), rng.value())
-    return v
+    # splitmix64's state is seed + k * gamma after k draws, so frame f's three values (draws 3f-2 .. 3f) are reached directly
+    rng = SplitMix64(seed + (3 * (frame - 1)) * 0x9E3779B97F4A7C15)
+    return rng.value(), rng.value(), rng.value()
 
 
 # --- camera (Scene1.unity:1777-1779,1804-1805; SURVEY.md A.2) -------------------------------------
