@@ -36,13 +36,18 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
-# algorithmic bytes per counted event (DESIGN.md "roofline")
-BYTES = {"tlas_nodes": 28, "blas_nodes": 64, "tri_tests": 48, "sphere_tests": 16, "hit_tri": 88, "hit_sphere": 40,
-         "hit_sky": 64, "pixels": 16}
+# ALGORITHMIC bytes per counted event — SURVEY.md §8(d)'s table, the figure `roofline.achieved` / `frac` are computed from:
+#   28 B object-level BVHNode, S_node = 64 B triangle-BVH node (this build's node: two child boxes), S_tri = 36 B world-space
+#   triangle, 16 B sphere test, 76 B triangle closest hit (3 normals + material), 40 B sphere hit, 16 B per pixel written.
+BYTES_8D = {"tlas_nodes": 28, "blas_nodes": 64, "tri_tests": 36, "sphere_tests": 16, "hit_tri": 76, "hit_sphere": 40, "pixels": 16}
+# what the kernel's records really are (reported separately as `padded_record_bytes_per_launch`): 48-B padded triangle
+# records (v0,e1,e2 as float4), 48 B of normals + 40 B material per triangle hit, and the 4 sky texels of a path's last bounce
+BYTES_PADDED = {"tlas_nodes": 28, "blas_nodes": 64, "tri_tests": 48, "sphere_tests": 16, "hit_tri": 88, "hit_sphere": 40,
+                "hit_sky": 64, "pixels": 16}
 
 
-def algorithmic_bytes(c: dict) -> int:
-    return sum(BYTES[k] * int(c[k]) for k in BYTES)
+def algorithmic_bytes(c: dict, table=BYTES_8D) -> int:
+    return sum(table[k] * int(c[k]) for k in table)
 
 
 def usable_cores() -> int:
@@ -64,6 +69,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="C3", help="BASELINE.json config to trace (C2..C5); the metric is quoted on C3")
     ap.add_argument("--kernel-mode", type=int, default=None, help="0 per-pixel, 1 per-bounce queues, 2 persistent, 3 persistent + phase-scheduled lanes (default)")
+    ap.add_argument("--frames-per-launch", type=int, default=None, help="library option frames_per_launch (0 auto, 1 = one launch per frame, 2..16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -102,13 +108,19 @@ def main():
     scene = scenes.CONFIGS[args.config](width, height)
 
     ctx = Context(dev_index)
-    # ONE explicit (non-default) stream shared by torch and the library: the HIP kernels, the pack/unpack kernels and the
-    # events that order the collective all live on it.  (torch's default stream has handle 0, which the C ABI reads as "use
-    # the library's own stream" — the two would then be unordered.)
-    main_stream = torch.cuda.Stream(device=device)
-    torch.cuda.set_stream(main_stream)
-    assert main_stream.cuda_stream != 0
-    ctx.set_stream(main_stream.cuda_stream)
+    main_stream = None
+    if world > 1:
+        # ONE explicit (non-default) stream shared by torch and the library: the HIP kernels, the pack/unpack kernels and the
+        # events that order the collective all live on it.  (torch's default stream has handle 0, which the C ABI reads as
+        # "use the library's own stream" — the two would then be unordered.)
+        main_stream = torch.cuda.Stream(device=device)
+        torch.cuda.set_stream(main_stream)
+        assert main_stream.cuda_stream != 0
+        ctx.set_stream(main_stream.cuda_stream)
+    # N = 1: the library works on its own stream, where it batches consecutive frames into one persistent launch
+    # (include/urt.h "frame batching"); fence() below submits and waits through the C ABI.
+    if args.frames_per_launch is not None:
+        ctx.set_option("frames_per_launch", args.frames_per_launch)
     if args.kernel_mode is not None:
         ctx.set_option("kernel_mode", args.kernel_mode)
     ctx.set_option("time_dispatch", 1)
@@ -179,6 +191,7 @@ def main():
             state["pending"] = None
 
     def fence():
+        ctx.synchronize()                     # submits the library's deferred frames and waits for its stream
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(device)
@@ -209,7 +222,11 @@ def main():
     roofline = None
     cpu = None
     if rank == 0:
+        # trace_ms = sum of the trace launches' own HIP-event durations (recorded by the library on the stream it launches
+        # on).  A batched launch traces several frames, so "per frame" is the launch time divided by its frames.
         kernel_ms = c["trace_ms"] / max(1, c["dispatches"])
+        launch_ms = c["trace_ms"] / max(1, c["launches"])
+        frames_per_launch = c["dispatches"] / max(1, c["launches"])
         ctx.set_option("count_stats", 1)
         ctx.set_option("time_dispatch", 0)
         master._frame = args.warmup
@@ -219,21 +236,31 @@ def main():
         cc = ctx.counters()
         ctx.set_option("count_stats", 0)
         assert cc["rays"] == c["rays"], "counting replay traced a different number of rays"
-        alg = algorithmic_bytes(cc) / max(1, cc["dispatches"])
-        achieved = alg / (kernel_ms * 1e-3) / 1e9
-        traffic = None
+        alg_frame = algorithmic_bytes(cc) / max(1, cc["dispatches"])
+        alg = alg_frame * frames_per_launch                            # per LAUNCH, like launch_ms
+        padded = algorithmic_bytes(cc, BYTES_PADDED) / max(1, cc["dispatches"]) * frames_per_launch
+        achieved = alg / (launch_ms * 1e-3) / 1e9
+        # HBM-side traffic is NOT measured in this run (PMC needs rocprofv3): it is the committed figure of the last profiled
+        # build, per launch of the same shape, or null when that profile is of another configuration / batch size
+        traffic, traffic_source = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")       # written from rocprofv3 --pmc passes (profiles/README.md)
         if os.path.exists(pmc):
             try:
                 j = json.load(open(pmc))
-                if j.get("config") == args.config and world == 1:
+                if j.get("config") == args.config and world == 1 and abs(j.get("frames_per_launch", 1) - frames_per_launch) < 0.51:
                     traffic = j.get("hbm_bytes_per_launch")
+                    traffic_source = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command, not this run)"
             except Exception:
                 traffic = None
-        roofline = {"bound": "hbm", "kernel": "trace: k_sched<false,256,false> (kernel_mode 3, the default)" if args.kernel_mode in (None, 3) else f"trace kernel of kernel_mode {args.kernel_mode}", "achieved": round(achieved, 1),
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "algorithmic_bytes_per_launch": int(alg), "kernel_ms": round(kernel_ms, 4),
-                    "bytes_per_ray": round(alg * cc["dispatches"] / max(1, cc["rays"]), 1)}
+        kname = "k_sched<false,256,false,false>" if scene.num_rays == 1 else "k_sched<false,256,false,true>"
+        roofline = {"bound": "hbm", "kernel": f"trace: {kname} (kernel_mode 3, the default)" if args.kernel_mode in (None, 3) else f"trace kernel of kernel_mode {args.kernel_mode}",
+                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": traffic, "traffic_source": traffic_source,
+                    "byte_table": "SURVEY.md 8(d): 28 B object node, 64 B BVH node, 36 B triangle, 16 B sphere, 76 B triangle hit, 40 B sphere hit, 16 B pixel",
+                    "algorithmic_bytes_per_launch": int(alg), "launch_ms": round(launch_ms, 4),
+                    "frames_per_launch": round(frames_per_launch, 2), "kernel_ms_per_frame": round(kernel_ms, 4),
+                    "padded_record_bytes_per_launch": int(padded), "frac_padded_records": round(padded / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "bytes_per_ray": round(alg_frame * cc["dispatches"] / max(1, cc["rays"]), 1)}
 
         # ---- CPU baseline: the oracle (scalar C++ port) on the host cores, bounded sample -------------------------
         if world == 1 and not args.no_cpu_baseline:

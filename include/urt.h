@@ -59,6 +59,14 @@ URT_API const char* urt_last_error(urt_context* ctx);
 URT_API int urt_context_set_stream(urt_context* ctx, void* hip_stream);
 /* Block until everything issued so far is complete. */
 URT_API int urt_synchronize(urt_context* ctx);
+/* Frame batching.  On its own stream the library DEFERS urt_shader_dispatch (default kernel) and the urt_blit_add /
+ * urt_texture_pack_rows calls that follow it, and traces several consecutive frames with one persistent launch (a 1080p
+ * frame is too small to fill 256 CUs through its 8-bounce tail; "frames_per_launch" below).  Every call that could observe
+ * an image (readback, synchronize, counters, Blit to another image, SetPixels, release, option changes, ...) submits the
+ * deferred work first, so results and ordering are exactly those of immediate execution (RM:806-820 is in-order).
+ * urt_flush submits the deferred work to the stream without waiting — for callers that synchronise by their own means
+ * (their own stream + events); with a caller-owned stream deferral is off unless "frames_per_launch" is set explicitly. */
+URT_API int urt_flush(urt_context* ctx);
 
 /* ---- ComputeBuffer ------------------------------------------------------------------------ */
 /* new ComputeBuffer(count, stride)                                   RM:247 */
@@ -139,10 +147,13 @@ typedef struct urt_counters {
   uint64_t hit_sky;       /* paths ended on the sky: 4 x 16 B texels */
   uint64_t pixels;        /* pixels written (16 B each) */
   uint64_t dispatches;    /* urt_shader_dispatch* calls since reset */
-  float trace_ms;         /* GPU time of the trace kernels of those dispatches (HIP events) */
+  float trace_ms;         /* GPU time of the trace kernels of those dispatches (HIP events; needs "time_dispatch") */
   uint32_t watchdog_trips; /* waves that hit a persistent kernel's iteration cap: always 0 unless there is a bug */
+  uint64_t launches;      /* trace-kernel launches those dispatches became (< dispatches when frames were batched) */
 } urt_counters;
-/* Options: "count_stats" (0/1: per-dispatch traversal counters, slower build of the kernel),
+/* Options: "frames_per_launch" (0 = auto: own stream -> up to 8 frames / ~16 M pixels per launch, caller's stream -> 1;
+ *                               1 = every dispatch is its own launch; 2..16 = batch that many, also on a caller's stream),
+ *          "count_stats" (0/1: per-dispatch traversal counters, slower build of the kernel),
  *          "time_dispatch" (0/1: bracket each dispatch with HIP events, read by urt_get_counters),
  *          "kernel_mode" (0 = one thread per pixel; 1 = one launch per bounce over compacted path queues;
  *                         2 = persistent waves with in-wave path regeneration;

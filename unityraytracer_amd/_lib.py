@@ -17,7 +17,7 @@ ERROR_NAMES = {1: "INVALID_ARGUMENT", 2: "INVALID_HANDLE", 3: "NO_DEVICE", 4: "H
 # every symbol include/urt.h declares (tests check that the .so exports each of them)
 ABI_SYMBOLS = [
     "urt_abi_version", "urt_device_count", "urt_context_create", "urt_context_destroy", "urt_last_error", "urt_context_set_stream",
-    "urt_synchronize", "urt_buffer_create", "urt_buffer_set_data", "urt_buffer_get_info", "urt_buffer_release", "urt_texture_create",
+    "urt_synchronize", "urt_flush", "urt_buffer_create", "urt_buffer_set_data", "urt_buffer_get_info", "urt_buffer_release", "urt_texture_create",
     "urt_texture_create_external", "urt_texture_set_pixels", "urt_texture_get_pixels", "urt_texture_get_info", "urt_texture_release",
     "urt_shader_set_buffer", "urt_shader_set_texture", "urt_shader_set_matrix", "urt_shader_set_vector", "urt_shader_set_float",
     "urt_shader_set_int", "urt_shader_dispatch", "urt_shader_dispatch_rows", "urt_blit_add", "urt_blit", "urt_texture_pack_rows",
@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
 
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("rays", "tlas_nodes", "blas_nodes", "tri_tests", "sphere_tests", "hit_tri", "hit_sphere",
-                                          "hit_ground", "hit_sky", "pixels", "dispatches")] + [("trace_ms", C.c_float), ("watchdog_trips", C.c_uint32)]
+                                          "hit_ground", "hit_sky", "pixels", "dispatches")] + [("trace_ms", C.c_float), ("watchdog_trips", C.c_uint32), ("launches", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -64,6 +64,7 @@ def load():
         "urt_last_error": ([vp], C.c_char_p),
         "urt_context_set_stream": ([vp, vp], i),
         "urt_synchronize": ([vp], i),
+        "urt_flush": ([vp], i),
         "urt_buffer_create": ([vp, i, i, C.POINTER(u64)], i),
         "urt_buffer_set_data": ([vp, u64, vp, i], i),
         "urt_buffer_get_info": ([vp, u64, pi, pi], i),

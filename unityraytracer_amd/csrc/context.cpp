@@ -34,8 +34,17 @@ struct Buffer {
 
 struct Texture {
   int w = 0, h = 0;
-  float4* dev = nullptr;
+  float4* dev = nullptr;        // where the CURRENT contents live: `own`, or a frame slot of the context's slab (a Result
+                                // texture is renamed to a fresh slot by every batched dispatch)
+  float4* own = nullptr;        // the allocation made at creation (or the caller's memory when external)
   bool external = false;
+  bool ptr_exposed = false;     // urt_texture_get_info handed out the device pointer: never renamed again
+  // What has written the image since its zero-filled creation.  A dispatch that covers only part of the image may be renamed
+  // to a (zero-filled) slab slot only while the pixels outside its region are still the zeros of creation, i.e. while
+  // nothing but dispatches of that SAME region has written the image.
+  bool other_writes = false;    // SetPixels / Blit destination / unpack_rows
+  int n_regions = 0;            // 0 none yet, 1 = every dispatch so far had region `rg`, 2 = mixed
+  int rg[4] = {0, 0, 0, 0};     // region_w, region_h, first_group_row, row_stride
 };
 
 enum BindSlot { B_MESHOBJECTS, B_VERTICES, B_INDICES, B_NORMALS, B_SPHERES, B_MESHBVH, B_SPHEREBVH, B_COUNT };
@@ -99,6 +108,35 @@ struct urt_context {
   int opt_lds_tlas = 1;                     // kernel_mode 3: object-level heaps, roots and spheres in LDS when small
   int opt_top_front = -1;                   // kernel_mode 3: top-of-forest walk inside the object-level phase (-1 = when the scene has several meshes)
   int opt_top_nodes = 64;                   // kernel_mode 3: triangle-BVH nodes kept in LDS (0 = none)
+
+  // ---- frame batching (kernel_mode 3) --------------------------------------------------------------------------------
+  // A 1080p frame is small for this chip: ~40 % of its kernel time is the drain of the last long paths.
+  // So dispatches are DEFERRED: consecutive frames that differ only in their per-frame uniforms (camera, _PixelOffset,
+  // _Seed) are collected and traced by ONE persistent launch whose lanes move on to the next frame's pixels as soon as
+  // the current frame is handed out.  Each frame's Result goes to its own slot of a slab (the Result texture is renamed
+  // per dispatch), the AdditionShader blits that follow the dispatches are deferred with them and run in order after the
+  // launch.  Everything else that could observe the images flushes first, so the in-order semantics of RM:806-820
+  // stay exactly observable.
+  int opt_frames_per_launch = 0;            // 0 = auto (own stream: up to 8 frames / ~16 M pixels per launch; caller's stream: 1), 1 = off, 2..16
+  uint64_t scene_epoch = 0;                 // bumps at every scene preparation
+  struct PostOp { int kind; int frame; urt_handle tex; urt_handle dst; float sample; int first_row, row_stride; void* dense; };   // kind 0 = blit_add(tex@frame -> dst), 1 = pack_rows(tex -> dense)
+  struct Pending {
+    int n = 0, limit = 1;
+    urt_handle tex = 0;                     // the Result texture of the batch
+    uint64_t scene_epoch = 0;
+    DevScene S{};
+    FrameParams P{};                        // frame 0's; the frames agree on everything but the table entries
+    FrameTable T{};
+    bool top_in_front = false, count = false;
+    std::vector<PostOp> ops;
+  } pend;
+  float4* slab = nullptr;                   // slab_frames x slab_stride float4: Result slots of the batched frames
+  size_t slab_stride = 0;
+  int slab_frames = 0;
+  urt_handle slab_tex = 0;                  // the texture whose `dev` may point into the slab
+  std::vector<hipEvent_t> event_pool;       // recycled timing events
+  hipEvent_t ev_switch = nullptr;           // orders the old stream before the new one in urt_context_set_stream
+  uint64_t launches = 0;                    // trace-kernel launches (a batched launch counts once)
 };
 
 namespace {
@@ -260,6 +298,7 @@ int prepare_scene(urt_context* ctx) {
   if ((size_t)(ctx->tlas_stack + ctx->blas_stack) * 64 * 4 * sizeof(int) > 150 * 1024)   // 4-wave workgroup; a CU has 160 KiB
     return fail(ctx, URT_ERR_SCENE, "traversal stacks exceed the LDS of a compute unit");
   ctx->scene_dirty = false;
+  ctx->scene_epoch++;
   return URT_OK;
 }
 
@@ -293,22 +332,174 @@ int resolve_timing(urt_context* ctx) {
   for (auto& pr : ctx->timing) {
     float ms = 0;
     if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) ctx->trace_ms += ms;
-    (void)hipEventDestroy(pr.first);
-    (void)hipEventDestroy(pr.second);
+    ctx->event_pool.push_back(pr.first);
+    ctx->event_pool.push_back(pr.second);
   }
   ctx->timing.clear();
   return URT_OK;
+}
+
+int take_event(urt_context* ctx, hipEvent_t* out) {
+  if (!ctx->event_pool.empty()) { *out = ctx->event_pool.back(); ctx->event_pool.pop_back(); return URT_OK; }
+  URT_HIP(ctx, hipEventCreate(out));
+  return URT_OK;
+}
+
+// ---- Result renaming: the slab of frame slots ---------------------------------------------------------------------------
+bool in_slab(urt_context* ctx, const Texture& t) {
+  return ctx->slab && t.dev >= ctx->slab && t.dev < ctx->slab + ctx->slab_stride * (size_t)ctx->slab_frames;
+}
+
+// Give a texture its own storage back (its current contents are copied out of the slab slot they live in).
+int detach_from_slab(urt_context* ctx, Texture& t) {
+  if (!in_slab(ctx, t)) return URT_OK;
+  URT_HIP(ctx, hipMemcpyAsync(t.own, t.dev, (size_t)t.w * t.h * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
+  t.dev = t.own;
+  return URT_OK;
+}
+
+// Slab of `frames` zero-filled slots for texture `h` (all work queued so far stays ordered before its first use: same stream).
+int ensure_slab(urt_context* ctx, urt_handle h, Texture& t, int frames) {
+  size_t stride = (size_t)t.w * (size_t)t.h;
+  if (ctx->slab && ctx->slab_tex == h && ctx->slab_stride == stride && ctx->slab_frames >= frames) return URT_OK;
+  if (ctx->slab_tex) {                                   // somebody's current contents may live in the old slab
+    auto it = ctx->textures.find(ctx->slab_tex);
+    if (it != ctx->textures.end()) { int rc = detach_from_slab(ctx, it->second); if (rc) return rc; }
+    ctx->slab_tex = 0;
+  }
+  if (!ctx->slab || ctx->slab_stride * (size_t)ctx->slab_frames < stride * (size_t)frames) {
+    if (ctx->slab) {
+      URT_HIP(ctx, hipStreamSynchronize(ctx->stream));   // queued kernels may still use the old slab
+      (void)hipFree(ctx->slab);
+      ctx->slab = nullptr; ctx->slab_frames = 0; ctx->slab_stride = 0;
+    }
+    URT_HIP(ctx, hipMalloc((void**)&ctx->slab, stride * (size_t)frames * sizeof(float4)));
+    ctx->slab_frames = frames;
+  } else {
+    ctx->slab_frames = (int)(ctx->slab_stride * (size_t)ctx->slab_frames / stride);    // same bytes, re-cut for this image size
+  }
+  ctx->slab_stride = stride;
+  URT_HIP(ctx, hipMemsetAsync(ctx->slab, 0, stride * (size_t)ctx->slab_frames * sizeof(float4), ctx->stream));   // a new RenderTexture is zero-filled
+  ctx->slab_tex = h;
+  return URT_OK;
+}
+
+// kernel_mode 3: what lives in the workgroup's LDS next to the stacks (fills P.top_nodes, P.lds_*, P.block_threads)
+void configure_sched(urt_context* ctx, const DevScene& S, FrameParams& P) {
+  // independent waves; the waves of a workgroup share one LDS copy of the top of the triangle-BVH forest, which shrinks
+  // until 5 waves/SIMD (what 96 VGPRs allow) fit the 160 KiB of a CU next to their traversal stacks
+  int t = std::min(std::min(ctx->opt_top_nodes, (int)kTopOrderNodes), ctx->n_blas_nodes);
+  // small object-level tables (<= 256 entries) also live in LDS: their walk is a chain of dependent fetches
+  P.lds_mesh = ctx->opt_lds_tlas && S.n_mesh_tlas > 0 && S.n_mesh_tlas <= 256 && S.n_meshes <= 256;
+  P.lds_small = P.lds_mesh && S.n_small > 0;
+  P.lds_sphere = ctx->opt_lds_tlas && S.n_sphere_tlas > 0 && S.n_sphere_tlas <= 256 && S.n_spheres <= 256;
+  bool shared = t > 0 || P.lds_mesh || P.lds_sphere;
+  P.block_threads = ctx->opt_sched_block > 0 ? ctx->opt_sched_block : (shared ? 256 : 64);   // nothing to share: single waves
+  P.top_nodes = t;
+  size_t groups = std::max<size_t>(1, (size_t)(ctx->opt_waves_per_cu > 0 ? ctx->opt_waves_per_cu : 20) / (size_t)(P.block_threads / 64));   // workgroups per CU that must fit
+  const size_t budget = 156 * 1024;                          // (a little of the 160 KiB goes to allocation granules)
+  while (P.top_nodes > 0 && sched_lds_bytes(S, P) * groups > budget) P.top_nodes /= 2;
+  if (sched_lds_bytes(S, P) * groups > budget) { P.lds_mesh = 0; P.lds_sphere = 0; P.lds_small = 0; }
+}
+
+// Launch the phase-scheduled trace kernel for P.n_frames frames (uniforms T) into result + f * P.frame_stride.
+int launch_sched_frames(urt_context* ctx, const DevScene& S, const FrameParams& P, const FrameTable& T, float4* result,
+                        bool top_in_front, bool count) {
+  int waves_per_block = P.block_threads / 64;
+  long want = ((long)P.tiles_x * P.n_strips * P.n_frames + waves_per_block - 1) / waves_per_block;
+  // resident waves per CU: every slot the registers allow (k_sched: 96 VGPRs -> 5 waves/SIMD = 20 per CU).  While the
+  // frame's work counter was one address, fewer and fatter waves were faster at 1080p (12 per CU); since it is sharded
+  // (kernels.hip wave_fetch_pixels) the full 20 win at every frame size measured (profiles/README.md).
+  int wpc = ctx->opt_waves_per_cu;
+  if (wpc <= 0) wpc = 20;
+  long resident = (long)ctx->n_cus * wpc / waves_per_block;
+  int nb = (int)std::max(1L, std::min(want, resident));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (ctx->opt_time_dispatch) {
+    int rc = take_event(ctx, &e0); if (rc) return rc;
+    rc = take_event(ctx, &e1); if (rc) return rc;
+    URT_HIP(ctx, hipEventRecord(e0, ctx->stream));
+  }
+  hipError_t le = launch_sched(S, P, T, result, ctx->d_counters, ctx->d_next, nb, top_in_front, count, ctx->stream);
+  if (ctx->opt_time_dispatch) {
+    (void)hipEventRecord(e1, ctx->stream);
+    ctx->timing.emplace_back(e0, e1);
+  }
+  ctx->launches++;
+  if (le != hipSuccess) return fail(ctx, URT_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(le));
+  return URT_OK;
+}
+
+// Submit the deferred frames: ONE trace launch, then the deferred blits in program order.  Runs of AdditionShader blits of
+// consecutive frames into one image are fused into a single pass (same per-pixel operations in the same order).
+int flush_pending(urt_context* ctx) {
+  urt_context::Pending& B = ctx->pend;
+  if (B.n == 0) return URT_OK;
+  int n = B.n;
+  B.n = 0;                                               // whatever happens below, the batch is gone
+  std::vector<urt_context::PostOp> ops;
+  ops.swap(B.ops);
+  URT_HIP(ctx, hipSetDevice(ctx->device));
+  FrameParams P = B.P;
+  P.n_frames = n;
+  P.frame_stride = (unsigned int)ctx->slab_stride;
+  int rc = launch_sched_frames(ctx, B.S, P, B.T, ctx->slab, B.top_in_front, B.count);
+  if (rc) return rc;
+  size_t i = 0;
+  while (i < ops.size()) {
+    const urt_context::PostOp& op = ops[i];
+    if (op.kind == 0) {
+      Texture* d = find_texture(ctx, op.dst);
+      if (!d) return fail(ctx, URT_ERR_INVALID_HANDLE, "deferred Blit: destination texture was released");
+      float samples[kMaxFramesPerLaunch];
+      size_t j = i;
+      int cnt = 0;
+      while (j < ops.size() && ops[j].kind == 0 && ops[j].dst == op.dst && ops[j].frame == op.frame + cnt && cnt < kMaxFramesPerLaunch) {
+        samples[cnt++] = ops[j].sample; j++;
+      }
+      const float4* src = ctx->slab + (size_t)op.frame * ctx->slab_stride;
+      hipError_t e = cnt == 1 ? launch_blit_add(src, d->dev, (size_t)d->w * d->h, samples[0], ctx->stream)
+                              : launch_blit_add_multi(src, ctx->slab_stride, cnt, samples, d->dev, (size_t)d->w * d->h, ctx->stream);
+      if (e != hipSuccess) return fail(ctx, URT_ERR_HIP, std::string("deferred Blit: ") + hipGetErrorString(e));
+      i = j;
+    } else {
+      Texture* t = find_texture(ctx, op.tex);
+      if (!t) return fail(ctx, URT_ERR_INVALID_HANDLE, "deferred pack_rows: texture was released");
+      const float4* img = op.tex == B.tex ? ctx->slab + (size_t)op.frame * ctx->slab_stride : t->dev;
+      int group_rows = (t->h + 7) / 8;
+      int n_strips = op.first_row < group_rows ? (group_rows - op.first_row + op.row_stride - 1) / op.row_stride : 0;
+      hipError_t e = launch_pack_rows(const_cast<float4*>(img), (float4*)op.dense, t->w, t->h, op.first_row, op.row_stride, n_strips, true, ctx->stream);
+      if (e != hipSuccess) return fail(ctx, URT_ERR_HIP, std::string("deferred pack_rows: ") + hipGetErrorString(e));
+      i++;
+    }
+  }
+  return URT_OK;
+}
+
+// frames one launch may hold for this dispatch
+int batch_limit(urt_context* ctx, const FrameParams& P) {
+  int lim = ctx->opt_frames_per_launch;
+  if (lim == 0) {
+    if (ctx->stream != ctx->own_stream) return 1;        // a caller that shares its stream expects the work ON the stream when dispatch returns
+    uint64_t px = (uint64_t)P.tiles_x * 64u * (uint64_t)P.n_strips;
+    lim = (int)std::min<uint64_t>(8, std::max<uint64_t>(1, (16u * 1024u * 1024u + px - 1) / std::max<uint64_t>(1, px)));
+  }
+  return std::max(1, std::min(lim, (int)kMaxFramesPerLaunch));
 }
 
 int do_dispatch(urt_context* ctx, int kernel, int gx, int gy, int gz, int first_row, int row_stride) {
   if (kernel != 0) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "kernel index must be 0 (CSMain)");
   if (gx < 0 || gy < 0 || gz < 0 || first_row < 0 || row_stride < 1)
     return fail(ctx, URT_ERR_INVALID_ARGUMENT, "negative thread-group count or bad strip arguments");
-  Texture* res = find_texture(ctx, ctx->t_result);
+  urt_handle res_h = ctx->t_result;
+  Texture* res = find_texture(ctx, res_h);
   if (!res) return fail(ctx, URT_ERR_UNBOUND, "Dispatch: no texture bound to \"Result\" (RM:803)");
   if (res->w > 65535 || res->h > 65535) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "Result larger than 65535 pixels per side");
   URT_HIP(ctx, hipSetDevice(ctx->device));
-  if (ctx->scene_dirty) { int rc = prepare_scene(ctx); if (rc) return rc; }
+  if (ctx->scene_dirty) {
+    int rc = flush_pending(ctx); if (rc) return rc;      // the deferred frames read the scene that is about to be replaced
+    rc = prepare_scene(ctx); if (rc) return rc;
+  }
   ctx->dispatches++;
   if (gx == 0 || gy == 0 || gz == 0) return URT_OK;
 
@@ -338,9 +529,10 @@ int do_dispatch(urt_context* ctx, int kernel, int gx, int gy, int gz, int first_
   P.n_strips = first_row < group_rows ? (group_rows - first_row + row_stride - 1) / row_stride : 0;
   P.tlas_stack = ctx->tlas_stack; P.blas_stack = ctx->blas_stack + ctx->opt_stack_pad; P.watchdog_steps = ctx->watchdog_steps;
   P.block_threads = ctx->opt_block_threads; P.xcd_run = ctx->opt_xcd_run; P.tile_order = ctx->opt_tile_order; P.refill_min = ctx->opt_refill_min; P.blas_min = ctx->opt_blas_min; P.blas_exit = ctx->opt_blas_exit; P.shade_min = ctx->opt_shade_min;
+  P.n_frames = 1; P.frame_stride = 0;
   if (P.n_strips == 0 || P.tiles_x == 0) return URT_OK;
-  if ((uint64_t)P.tiles_x * (uint64_t)P.n_strips * 64u >= 0xffffffffull)
-    return fail(ctx, URT_ERR_INVALID_ARGUMENT, "Dispatch: more than 2^32 pixel slots in one dispatch");
+  if ((uint64_t)P.tiles_x * (uint64_t)P.n_strips * 64u * (uint64_t)kMaxFramesPerLaunch >= 0xffffffffull)
+    return fail(ctx, URT_ERR_INVALID_ARGUMENT, "Dispatch: too many pixel slots in one dispatch");
 
   // region pixels this dispatch writes (threads outside Result write nothing, RS:468)
   {
@@ -353,68 +545,94 @@ int do_dispatch(urt_context* ctx, int kernel, int gx, int gy, int gz, int first_
   }
   bool degenerate = P.num_bounces <= 0 || P.num_rays <= 0;      // loops that never run: the megakernel handles them literally
   int mode = degenerate ? 0 : ctx->opt_kernel_mode;
-  if (mode == 1) {
-    size_t n_paths = (size_t)P.tiles_x * 64 * (size_t)P.n_strips;
-    int rc = ensure_queues(ctx, n_paths, (size_t)P.num_rays * (size_t)(P.num_bounces + 1));
-    if (rc) return rc;
-  }
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (ctx->opt_time_dispatch) {
-    URT_HIP(ctx, hipEventCreate(&e0));
-    URT_HIP(ctx, hipEventCreate(&e1));
-    URT_HIP(ctx, hipEventRecord(e0, ctx->stream));
-  }
   bool count = ctx->opt_count_stats != 0;
-  hipError_t le;
-  if (mode == 1) le = launch_wavefront(S, P, ctx->q, res->dev, ctx->d_counters, count, ctx->stream);
-  else if (mode == 2 || mode == 3) {
-    if (mode == 3) {
-      // independent waves; the waves of a workgroup share one LDS copy of the top of the triangle-BVH forest, which shrinks
-      // until 5 waves/SIMD (what 96 VGPRs allow) fit the 160 KiB of a CU next to their traversal stacks
-      int t = std::min(std::min(ctx->opt_top_nodes, (int)kTopOrderNodes), ctx->n_blas_nodes);
-      // small object-level tables (<= 256 entries) also live in LDS: their walk is a chain of dependent fetches
-      P.lds_mesh = ctx->opt_lds_tlas && S.n_mesh_tlas > 0 && S.n_mesh_tlas <= 256 && S.n_meshes <= 256;
-      P.lds_small = P.lds_mesh && S.n_small > 0;
-      P.lds_sphere = ctx->opt_lds_tlas && S.n_sphere_tlas > 0 && S.n_sphere_tlas <= 256 && S.n_spheres <= 256;
-      bool shared = t > 0 || P.lds_mesh || P.lds_sphere;
-      P.block_threads = ctx->opt_sched_block > 0 ? ctx->opt_sched_block : (shared ? 256 : 64);   // nothing to share: single waves
-      P.top_nodes = t;
-      size_t groups = std::max<size_t>(1, (size_t)(ctx->opt_waves_per_cu > 0 ? ctx->opt_waves_per_cu : 20) / (size_t)(P.block_threads / 64));   // workgroups per CU that must fit
-      const size_t budget = 156 * 1024;                          // (a little of the 160 KiB goes to allocation granules)
-      while (P.top_nodes > 0 && sched_lds_bytes(S, P) * groups > budget) P.top_nodes /= 2;
-      if (sched_lds_bytes(S, P) * groups > budget) { P.lds_mesh = 0; P.lds_sphere = 0; P.lds_small = 0; }
+  const int region[4] = {P.region_w, P.region_h, first_row, row_stride};
+  const bool full_cover = P.region_w == res->w && P.region_h == res->h && first_row == 0 && row_stride == 1;
+
+  if (mode == 3) {
+    configure_sched(ctx, S, P);
+    bool top_in_front = ctx->opt_top_front < 0 ? S.n_meshes > 1 : ctx->opt_top_front != 0;
+    FrameUniforms fu{};
+    std::memcpy(fu.c2w, P.c2w, sizeof fu.c2w);
+    std::memcpy(fu.invp, P.invp, sizeof fu.invp);
+    fu.pixel_off_x = P.pixel_off_x; fu.pixel_off_y = P.pixel_off_y; fu.seed = P.seed;
+    // May this dispatch be renamed to a fresh slab slot?  Its unwritten pixels must read as before: none (full cover), or
+    // still the zeros of creation (only dispatches of this same region ever wrote the image).
+    bool same_region = res->n_regions == 1 && std::memcmp(res->rg, region, sizeof region) == 0;
+    bool renamable = !res->external && !res->ptr_exposed && (full_cover || (!res->other_writes && (res->n_regions == 0 || same_region)));
+    int limit = renamable ? batch_limit(ctx, P) : 1;
+    urt_context::Pending& B = ctx->pend;
+    if (B.n > 0) {
+      const FrameParams& Q = B.P;
+      bool same = B.tex == res_h && B.scene_epoch == ctx->scene_epoch && B.S.sky == S.sky && B.S.sky_w == S.sky_w && B.S.sky_h == S.sky_h &&
+                  B.count == count && B.top_in_front == top_in_front && Q.num_bounces == P.num_bounces && Q.num_rays == P.num_rays &&
+                  Q.width == P.width && Q.height == P.height && Q.region_w == P.region_w && Q.region_h == P.region_h &&
+                  Q.first_group_row == P.first_group_row && Q.row_stride == P.row_stride && B.n < B.limit && limit > 1;
+      if (!same) { int rc = flush_pending(ctx); if (rc) return rc; }
     }
-    int waves_per_block = P.block_threads / 64;
-    long want = ((long)P.tiles_x * P.n_strips + waves_per_block - 1) / waves_per_block;
-    // resident waves per CU: every slot the registers allow (k_sched: 96 VGPRs -> 5 waves/SIMD = 20 per CU).  While the
-    // frame's work counter was one address, fewer and fatter waves were faster at 1080p (12 per CU); since it is sharded
-    // (kernels.hip wave_fetch_pixels) the full 20 win at every frame size measured (profiles/README.md).
-    int wpc = ctx->opt_waves_per_cu;
-    if (wpc <= 0) wpc = 20;
-    long resident = (long)ctx->n_cus * wpc / waves_per_block;
-    int nb = (int)std::max(1L, std::min(want, resident));
-    le = mode == 2 ? launch_persist(S, P, res->dev, ctx->d_counters, ctx->d_next, nb, count, ctx->stream)
-                   : launch_sched(S, P, res->dev, ctx->d_counters, ctx->d_next, nb, ctx->opt_top_front < 0 ? S.n_meshes > 1 : ctx->opt_top_front != 0, count, ctx->stream);
-  } else if (mode == 4) {
-    // one wave per workgroup; residency is bounded by the LDS one wave's path pool takes (kernels.hip k_pool)
-    P.block_threads = 64;
-    P.refill_min = ctx->opt_pool_refill; P.blas_min = ctx->opt_pool_blas_min; P.blas_exit = ctx->opt_pool_blas_exit;
-    P.pool_inloop = ctx->opt_pool_inloop; P.pool_other_min = ctx->opt_pool_other_min;
-    int k = ctx->opt_pool_k;
-    size_t lds = pool_lds_bytes(P, k);
-    while (k > 1 && lds > 160 * 1024) { k--; lds = pool_lds_bytes(P, k); }
-    if (lds > 160 * 1024) return fail(ctx, URT_ERR_OUT_OF_MEMORY, "kernel_mode 4: the scene's traversal stacks do not fit the LDS of one CU; use kernel_mode 3");
-    int fit = (int)std::max<size_t>(1, (160 * 1024) / lds);
-    int wpc = ctx->opt_waves_per_cu > 0 ? ctx->opt_waves_per_cu : fit;
-    long want = ((long)P.tiles_x * P.n_strips * 64 + 64L * k - 1) / (64L * k);
-    int nb = (int)std::max(1L, std::min(want, (long)ctx->n_cus * wpc));
-    le = launch_pool(S, P, res->dev, ctx->d_counters, ctx->d_next, nb, k, count, ctx->stream);
-  } else le = launch_mega(S, P, res->dev, ctx->d_counters, count, ctx->stream);
-  if (ctx->opt_time_dispatch) {
-    (void)hipEventRecord(e1, ctx->stream);
-    ctx->timing.emplace_back(e0, e1);
+    if (limit <= 1) {                                     // not batched: trace this frame now, straight into the texture
+      FrameTable T{};
+      T.f[0] = fu;
+      int rc = launch_sched_frames(ctx, S, P, T, res->dev, top_in_front, count);
+      if (rc) return rc;
+    } else {
+      if (B.n == 0) {
+        int rc = ensure_slab(ctx, res_h, *res, limit); if (rc) return rc;
+        B.limit = std::min(limit, ctx->slab_frames);
+        B.tex = res_h; B.scene_epoch = ctx->scene_epoch; B.S = S; B.P = P; B.top_in_front = top_in_front; B.count = count;
+      }
+      B.T.f[B.n] = fu;
+      res->dev = ctx->slab + (size_t)B.n * ctx->slab_stride;   // Result now names this frame's slot
+      B.n++;
+    }
+  } else {
+    int rc = flush_pending(ctx); if (rc) return rc;
+    if (mode == 1) {
+      size_t n_paths = (size_t)P.tiles_x * 64 * (size_t)P.n_strips;
+      rc = ensure_queues(ctx, n_paths, (size_t)P.num_rays * (size_t)(P.num_bounces + 1));
+      if (rc) return rc;
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ctx->opt_time_dispatch) {
+      rc = take_event(ctx, &e0); if (rc) return rc;
+      rc = take_event(ctx, &e1); if (rc) return rc;
+      URT_HIP(ctx, hipEventRecord(e0, ctx->stream));
+    }
+    hipError_t le;
+    if (mode == 1) le = launch_wavefront(S, P, ctx->q, res->dev, ctx->d_counters, count, ctx->stream);
+    else if (mode == 2) {
+      int waves_per_block = P.block_threads / 64;
+      long want = ((long)P.tiles_x * P.n_strips + waves_per_block - 1) / waves_per_block;
+      int wpc = ctx->opt_waves_per_cu;
+      if (wpc <= 0) wpc = 20;
+      long resident = (long)ctx->n_cus * wpc / waves_per_block;
+      int nb = (int)std::max(1L, std::min(want, resident));
+      le = launch_persist(S, P, res->dev, ctx->d_counters, ctx->d_next, nb, count, ctx->stream);
+    } else if (mode == 4) {
+      // one wave per workgroup; residency is bounded by the LDS one wave's path pool takes (kernels.hip k_pool)
+      P.block_threads = 64;
+      P.refill_min = ctx->opt_pool_refill; P.blas_min = ctx->opt_pool_blas_min; P.blas_exit = ctx->opt_pool_blas_exit;
+      P.pool_inloop = ctx->opt_pool_inloop; P.pool_other_min = ctx->opt_pool_other_min;
+      int k = ctx->opt_pool_k;
+      size_t lds = pool_lds_bytes(P, k);
+      while (k > 1 && lds > 160 * 1024) { k--; lds = pool_lds_bytes(P, k); }
+      if (lds > 160 * 1024) return fail(ctx, URT_ERR_OUT_OF_MEMORY, "kernel_mode 4: the scene's traversal stacks do not fit the LDS of one CU; use kernel_mode 3");
+      int fit = (int)std::max<size_t>(1, (160 * 1024) / lds);
+      int wpc = ctx->opt_waves_per_cu > 0 ? ctx->opt_waves_per_cu : fit;
+      long want = ((long)P.tiles_x * P.n_strips * 64 + 64L * k - 1) / (64L * k);
+      int nb = (int)std::max(1L, std::min(want, (long)ctx->n_cus * wpc));
+      le = launch_pool(S, P, res->dev, ctx->d_counters, ctx->d_next, nb, k, count, ctx->stream);
+    } else le = launch_mega(S, P, res->dev, ctx->d_counters, count, ctx->stream);
+    if (ctx->opt_time_dispatch) {
+      (void)hipEventRecord(e1, ctx->stream);
+      ctx->timing.emplace_back(e0, e1);
+    }
+    ctx->launches++;
+    if (le != hipSuccess) return fail(ctx, URT_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(le));
   }
-  if (le != hipSuccess) return fail(ctx, URT_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(le));
+  // remember what has written the image (see Texture)
+  if (res->n_regions == 0) { res->n_regions = 1; std::memcpy(res->rg, region, sizeof region); }
+  else if (std::memcmp(res->rg, region, sizeof region) != 0) res->n_regions = 2;
   return URT_OK;
 }
 
@@ -422,7 +640,7 @@ int do_dispatch(urt_context* ctx, int kernel, int gx, int gy, int gz, int first_
 
 extern "C" {
 
-int urt_abi_version(void) { return 1; }
+int urt_abi_version(void) { return 2; }
 
 int urt_device_count(int* out_count) {
   if (!out_count) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "out_count is NULL");
@@ -462,10 +680,14 @@ int urt_context_create(int device, urt_context** out_ctx) {
 int urt_context_destroy(urt_context* ctx) {
   if (!ctx) return URT_OK;
   (void)hipSetDevice(ctx->device);
+  (void)flush_pending(ctx);
   (void)hipStreamSynchronize(ctx->stream);
   resolve_timing(ctx);
   free_scene(ctx);
-  for (auto& kv : ctx->textures) if (!kv.second.external && kv.second.dev) (void)hipFree(kv.second.dev);
+  for (auto& kv : ctx->textures) if (!kv.second.external && kv.second.own) (void)hipFree(kv.second.own);
+  if (ctx->slab) (void)hipFree(ctx->slab);
+  for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
+  if (ctx->ev_switch) (void)hipEventDestroy(ctx->ev_switch);
   for (int a = 0; a < 2; a++) for (int r = 0; r < 4; r++) if (ctx->q.s[a][r]) (void)hipFree(ctx->q.s[a][r]);
   if (ctx->q.counts) (void)hipFree(ctx->q.counts);
   if (ctx->zero_sky) (void)hipFree(ctx->zero_sky);
@@ -481,14 +703,29 @@ const char* urt_last_error(urt_context* ctx) { return ctx ? ctx->err.c_str() : g
 int urt_context_set_stream(urt_context* ctx, void* hip_stream) {
   if (!ctx) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "ctx is NULL");
   URT_HIP(ctx, hipSetDevice(ctx->device));
-  URT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  { int rc = flush_pending(ctx); if (rc) return rc; }
+  hipStream_t to = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  if (to == ctx->stream) return URT_OK;
+  // no host synchronisation: everything issued so far on the old stream is ordered before whatever is issued on the new
+  // one by an event (a caller that ping-pongs between a render and a communication stream must not stall on either)
+  if (!ctx->ev_switch) URT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_switch, hipEventDisableTiming));
+  URT_HIP(ctx, hipEventRecord(ctx->ev_switch, ctx->stream));
+  URT_HIP(ctx, hipStreamWaitEvent(to, ctx->ev_switch, 0));
+  ctx->stream = to;
   return URT_OK;
+}
+
+int urt_flush(urt_context* ctx) {
+  if (!ctx) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  URT_GUARD_BEGIN
+  return flush_pending(ctx);
+  URT_GUARD_END(ctx)
 }
 
 int urt_synchronize(urt_context* ctx) {
   if (!ctx) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "ctx is NULL");
   URT_HIP(ctx, hipSetDevice(ctx->device));
+  { int rc = flush_pending(ctx); if (rc) return rc; }
   URT_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return URT_OK;
 }
@@ -549,12 +786,13 @@ static int texture_create_impl(urt_context* ctx, int width, int height, void* ex
   URT_HIP(ctx, hipSetDevice(ctx->device));
   Texture t; t.w = width; t.h = height;
   size_t bytes = (size_t)width * (size_t)height * sizeof(float4);
-  if (ext) { t.dev = (float4*)ext; t.external = true; }
+  if (ext) { t.dev = (float4*)ext; t.external = true; t.other_writes = true; /* caller memory: contents unknown */ }
   else {
     URT_HIP(ctx, hipMalloc((void**)&t.dev, bytes));
     hipError_t e = hipMemsetAsync(t.dev, 0, bytes, ctx->stream);
     if (e != hipSuccess) { (void)hipFree(t.dev); return fail(ctx, URT_ERR_HIP, std::string("hipMemsetAsync: ") + hipGetErrorString(e)); }
   }
+  t.own = t.dev;
   urt_handle h = ctx->next_id++;
   ctx->textures.emplace(h, t);
   *out_texture = h;
@@ -577,6 +815,8 @@ int urt_texture_set_pixels(urt_context* ctx, urt_handle texture, const float* rg
   if (!t) return fail(ctx, URT_ERR_INVALID_HANDLE, "unknown texture handle");
   if (!rgba) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "rgba is NULL");
   URT_HIP(ctx, hipSetDevice(ctx->device));
+  { int rc = flush_pending(ctx); if (rc) return rc; }
+  t->other_writes = true;
   URT_HIP(ctx, hipMemcpyAsync(t->dev, rgba, (size_t)t->w * t->h * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
   URT_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return URT_OK;
@@ -588,6 +828,7 @@ int urt_texture_get_pixels(urt_context* ctx, urt_handle texture, float* rgba) {
   if (!t) return fail(ctx, URT_ERR_INVALID_HANDLE, "unknown texture handle");
   if (!rgba) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "rgba is NULL");
   URT_HIP(ctx, hipSetDevice(ctx->device));
+  { int rc = flush_pending(ctx); if (rc) return rc; }
   URT_HIP(ctx, hipMemcpyAsync(rgba, t->dev, (size_t)t->w * t->h * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
   URT_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return URT_OK;
@@ -599,7 +840,15 @@ int urt_texture_get_info(urt_context* ctx, urt_handle texture, int* out_width, i
   if (!t) return fail(ctx, URT_ERR_INVALID_HANDLE, "unknown texture handle");
   if (out_width) *out_width = t->w;
   if (out_height) *out_height = t->h;
-  if (out_device_ptr) *out_device_ptr = t->dev;
+  if (out_device_ptr) {
+    // the caller is going to touch the memory itself: submit what is deferred, give the image back its own (stable)
+    // storage and never rename it again
+    URT_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = flush_pending(ctx); if (rc) return rc;
+    rc = detach_from_slab(ctx, *t); if (rc) return rc;
+    t->ptr_exposed = true;
+    *out_device_ptr = t->dev;
+  }
   return URT_OK;
 }
 
@@ -608,8 +857,10 @@ int urt_texture_release(urt_context* ctx, urt_handle texture) {
   auto it = ctx->textures.find(texture);
   if (it == ctx->textures.end()) return fail(ctx, URT_ERR_INVALID_HANDLE, "Release: unknown texture handle");
   URT_HIP(ctx, hipSetDevice(ctx->device));
+  { int rc = flush_pending(ctx); if (rc) return rc; }
   URT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if (!it->second.external && it->second.dev) (void)hipFree(it->second.dev);
+  if (!it->second.external && it->second.own) (void)hipFree(it->second.own);
+  if (ctx->slab_tex == texture) ctx->slab_tex = 0;
   if (ctx->t_sky == texture) ctx->t_sky = 0;
   if (ctx->t_result == texture) ctx->t_result = 0;
   ctx->textures.erase(it);
@@ -698,8 +949,19 @@ int urt_blit_add(urt_context* ctx, urt_handle src, urt_handle dst, float sample)
   if (!s || !d) return fail(ctx, URT_ERR_INVALID_HANDLE, "Blit: unknown texture handle");
   if (s->w != d->w || s->h != d->h) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "Blit: source and destination sizes differ");
   URT_HIP(ctx, hipSetDevice(ctx->device));
+  URT_GUARD_BEGIN
+  d->other_writes = true;
+  urt_context::Pending& B = ctx->pend;
+  if (B.n > 0 && src == B.tex && dst != src && (const float4*)d->dev != B.S.sky) {
+    // the source is a frame that has not been traced yet: the blend is deferred with it (flush_pending runs it in order)
+    B.ops.push_back(urt_context::PostOp{0, B.n - 1, src, dst, sample, 0, 1, nullptr});
+    if (B.n >= B.limit) return flush_pending(ctx);        // the batch is full and its last frame's blend is in: go
+    return URT_OK;
+  }
+  { int rc = flush_pending(ctx); if (rc) return rc; }
   URT_HIP(ctx, launch_blit_add(s->dev, d->dev, (size_t)s->w * s->h, sample, ctx->stream));
   return URT_OK;
+  URT_GUARD_END(ctx)
 }
 
 int urt_blit(urt_context* ctx, urt_handle src, urt_handle dst) {
@@ -709,6 +971,8 @@ int urt_blit(urt_context* ctx, urt_handle src, urt_handle dst) {
   if (!s || !d) return fail(ctx, URT_ERR_INVALID_HANDLE, "Blit: unknown texture handle");
   if (s->w != d->w || s->h != d->h) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "Blit: source and destination sizes differ");
   URT_HIP(ctx, hipSetDevice(ctx->device));
+  { int rc = flush_pending(ctx); if (rc) return rc; }
+  d->other_writes = true;
   URT_HIP(ctx, hipMemcpyAsync(d->dev, s->dev, (size_t)s->w * s->h * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
   return URT_OK;
 }
@@ -724,6 +988,15 @@ static int pack_impl(urt_context* ctx, urt_handle texture, int first_group_row, 
   if (out_bytes) *out_bytes = (uint64_t)n_strips * 8u * (uint64_t)t->w * sizeof(float4);
   if (!dense) return URT_OK;   // size query
   URT_HIP(ctx, hipSetDevice(ctx->device));
+  URT_GUARD_BEGIN
+  urt_context::Pending& B = ctx->pend;
+  if (to_dense && B.n > 0) {     // reads an image that deferred work is still going to write: deferred with it, in order
+    B.ops.push_back(urt_context::PostOp{1, B.n - 1, texture, 0, 0.0f, first_group_row, row_stride, dense});
+    return URT_OK;
+  }
+  { int rc = flush_pending(ctx); if (rc) return rc; }
+  if (!to_dense) t->other_writes = true;
+  URT_GUARD_END(ctx)
   URT_HIP(ctx, launch_pack_rows(t->dev, (float4*)dense, t->w, t->h, first_group_row, row_stride, n_strips, to_dense, ctx->stream));
   return URT_OK;
 }
@@ -742,7 +1015,11 @@ int urt_texture_unpack_rows(urt_context* ctx, urt_handle texture, int first_grou
 int urt_set_option(urt_context* ctx, const char* name, int value) {
   if (!ctx) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "ctx is NULL");
   if (!name) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "option name is NULL");
-  if (std::strcmp(name, "count_stats") == 0) ctx->opt_count_stats = value ? 1 : 0;
+  { (void)hipSetDevice(ctx->device); int rc = flush_pending(ctx); if (rc) return rc; }   // deferred frames run with the options they were dispatched under
+  if (std::strcmp(name, "frames_per_launch") == 0) {
+    if (value < 0 || value > kMaxFramesPerLaunch) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "frames_per_launch must be in [0, 16] (0 = auto)");
+    ctx->opt_frames_per_launch = value;
+  } else if (std::strcmp(name, "count_stats") == 0) ctx->opt_count_stats = value ? 1 : 0;
   else if (std::strcmp(name, "time_dispatch") == 0) ctx->opt_time_dispatch = value ? 1 : 0;
   else if (std::strcmp(name, "kernel_mode") == 0) {
     if (value < 0 || value > 4) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "kernel_mode must be 0..4");
@@ -815,6 +1092,7 @@ int urt_get_counters(urt_context* ctx, urt_counters* out) {
   if (!ctx) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "ctx is NULL");
   if (!out) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "out is NULL");
   URT_HIP(ctx, hipSetDevice(ctx->device));
+  { int rc = flush_pending(ctx); if (rc) return rc; }
   URT_HIP(ctx, hipStreamSynchronize(ctx->stream));
   resolve_timing(ctx);
   std::vector<DevCounters> shards(kCounterShards);
@@ -828,6 +1106,7 @@ int urt_get_counters(urt_context* ctx, urt_counters* out) {
   }
   out->pixels = ctx->pixels_dispatched;
   out->dispatches = ctx->dispatches;
+  out->launches = ctx->launches;
   out->trace_ms = ctx->trace_ms;
   return URT_OK;
 }
@@ -835,10 +1114,12 @@ int urt_get_counters(urt_context* ctx, urt_counters* out) {
 int urt_reset_counters(urt_context* ctx) {
   if (!ctx) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "ctx is NULL");
   URT_HIP(ctx, hipSetDevice(ctx->device));
+  { int rc = flush_pending(ctx); if (rc) return rc; }
   URT_HIP(ctx, hipStreamSynchronize(ctx->stream));
   resolve_timing(ctx);
   URT_HIP(ctx, hipMemset(ctx->d_counters, 0, sizeof(DevCounters) * kCounterShards));
   ctx->dispatches = 0;
+  ctx->launches = 0;
   ctx->pixels_dispatched = 0;
   ctx->trace_ms = 0;
   return URT_OK;

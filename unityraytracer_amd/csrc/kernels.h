@@ -15,8 +15,13 @@ hipError_t launch_persist(const DevScene& S, const FrameParams& P, float4* resul
                           int n_blocks, bool count, hipStream_t st);
 // mode 3: persistent waves whose lanes are scheduled by phase (FRONT / BLAS / SHADE) inside the wave
 // top_in_front: walk the LDS-resident top of the BVH forest inside the object-level phase (pays in multi-mesh scenes)
-hipError_t launch_sched(const DevScene& S, const FrameParams& P, float4* result, DevCounters* ctr, unsigned int* next,
-                        int n_blocks, bool top_in_front, bool count, hipStream_t st);
+// One launch traces P.n_frames consecutive frames (uniforms in T, Result images P.frame_stride apart from `result`).
+hipError_t launch_sched(const DevScene& S, const FrameParams& P, const FrameTable& T, float4* result, DevCounters* ctr,
+                        unsigned int* next, int n_blocks, bool top_in_front, bool count, hipStream_t st);
+// fused AdditionShader blends of n consecutive frames into one image: dst = blend(... blend(blend(dst, src_0), src_1) ..., src_{n-1})
+// in that order per pixel — the same operations as n launch_blit_add calls; src_f = src + f * frame_stride
+hipError_t launch_blit_add_multi(const float4* src, size_t frame_stride, int n, const float* samples, float4* dst, size_t n_pixels,
+                                 hipStream_t st);
 size_t sched_lds_bytes(const DevScene& S, const FrameParams& P);          // dynamic LDS of one workgroup (4 waves) of mode 3
 // mode 4: persistent waves over a pool of 64*k paths per wave kept in LDS, phases run on compacted lanes
 hipError_t launch_pool(const DevScene& S, const FrameParams& P, float4* result, DevCounters* ctr, unsigned int* next,

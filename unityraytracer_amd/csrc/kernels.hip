@@ -433,8 +433,43 @@ __device__ __forceinline__ void camera_ray(const FrameParams& P, int x, int y, f
   dir = mul_m4_k(c2w, dir.x, dir.y, dir.z, 0.0f);
   d = normalize(dir);
 }
+// The same for a batched launch (mode 3): the uniforms of the path's frame come from the launch's frame table, a by-value
+// kernel argument at byte offset T_OFF of the kernarg segment.  `f` must be wave-uniform.
+template <unsigned T_OFF>
+__device__ __forceinline__ void camera_ray_frame(int f, const FrameParams& P, int x, int y, bool new_pixel, float& seed, v3& o, v3& d) {
+  kfloatp q = kernarg_floats((unsigned)__builtin_amdgcn_readfirstlane((int)(T_OFF + (unsigned)f * (unsigned)sizeof(FrameUniforms))));
+  if (new_pixel) seed = q[34];                     // RS:16: every pixel starts from the frame's _Seed; it carries over between a pixel's rays (RS:444)
+  float px = (float)x, py = (float)y;
+  float r0 = rand_next(seed, px, py);
+  float r1 = rand_next(seed, px, py);
+  float u = (px + r0 + q[32]) / (float)P.width * 2.0f - 1.0f;
+  float v = (py + r1 + q[33]) / (float)P.height * 2.0f - 1.0f;
+  kfloatp c2w = q, invp = q + 16;
+  o = mul_m4_k(c2w, 0.0f, 0.0f, 0.0f, 1.0f);
+  v3 dir = mul_m4_k(invp, u, v, 0.0f, 1.0f);
+  dir = mul_m4_k(c2w, dir.x, dir.y, dir.z, 0.0f);
+  d = normalize(dir);
+}
+static_assert(__builtin_offsetof(FrameUniforms, invp) == 64 && __builtin_offsetof(FrameUniforms, pixel_off_x) == 128 &&
+              __builtin_offsetof(FrameUniforms, seed) == 136, "camera_ray_frame indexes the table as floats");
+
+// Runs body(frame index as a wave-uniform value, lane predicate) once per distinct frame among the lanes of `pred` (almost
+// always one: a wave's refill straddles two frames only at a frame boundary of the launch).
+template <typename F>
+__device__ __forceinline__ void for_each_frame(bool pred, int frame, F&& body) {
+  unsigned long long todo = __ballot(pred);
+  while (todo) {
+    int f = __builtin_amdgcn_readlane(frame, __builtin_ctzll(todo));
+    bool mine = pred && frame == f;
+    body(f, mine);
+    todo &= ~__ballot(mine);
+  }
+}
+
 // kernels take (DevScene, FrameParams, ...) or (FrameParams, ...): by-value aggregates are laid out like C struct members
 static constexpr unsigned kPOffAfterScene = (unsigned)((sizeof(DevScene) + alignof(FrameParams) - 1) / alignof(FrameParams) * alignof(FrameParams));
+// k_sched takes (DevScene, FrameParams, FrameTable, ...)
+static constexpr unsigned kTOffAfterParams = (unsigned)((kPOffAfterScene + sizeof(FrameParams) + alignof(FrameTable) - 1) / alignof(FrameTable) * alignof(FrameTable));
 
 // tile -> pixel: one 8x8 tile per wave (the reference's [numthreads(8,8,1)] group, RS:431).
 // Blocks are dealt round-robin to the 8 XCDs (b % 8 shares an XCD, each XCD has a private 4 MiB L2).
@@ -558,8 +593,11 @@ __device__ __forceinline__ bool slot_pixel(const FrameParams& P, unsigned int ti
 
 // The wave takes popcount(want) slots with ONE atomic; each lane of `want` gets its own slot (prefix popcount).  Returns true
 // and the pixel for lanes that received a valid one.  Sets `exhausted` when every shard is dry.
+// Batched launches (mode 3): the work is the concatenation of the frames' tile sequences (ntiles = frames x tiles_per_frame,
+// frame-major, so the launch sweeps frame 0 first); `frame` receives the frame a slot belongs to.
 __device__ __forceinline__ bool wave_fetch_pixels(const FrameParams& P, unsigned long long want, bool mine, unsigned int* next,
-                                                  unsigned int ntiles, WorkCursor& wc, bool& exhausted, int& x, int& y) {
+                                                  unsigned int ntiles, WorkCursor& wc, bool& exhausted, int& x, int& y,
+                                                  unsigned int tiles_per_frame = 0, int* frame = nullptr) {
   const int lane = threadIdx.x & 63;
   unsigned int n = (unsigned int)__popcll(want);
   const unsigned int G = (unsigned int)P.xcd_run;
@@ -581,6 +619,7 @@ __device__ __forceinline__ bool wave_fetch_pixels(const FrameParams& P, unsigned
   unsigned int local = base + (unsigned int)__popcll(want & ((1ull << lane) - 1ull));
   if (!mine || local >= own) return false;
   unsigned int tile = shard_tile(shard, local >> 6, G);
+  if (frame) { unsigned int f = tile / tiles_per_frame; tile -= f * tiles_per_frame; *frame = (int)f; ntiles = tiles_per_frame; }
   if (P.tile_order == 1) tile = ntiles - 1u - tile;            // top strip first
   return slot_pixel(P, tile, local & 63u, x, y);
 }
@@ -776,8 +815,11 @@ static constexpr unsigned int kWatchdogIters = 1u << 24;    // scheduler trips p
 #ifndef URT_SCHED_OCC
 #define URT_SCHED_OCC 5
 #endif
-template <bool COUNT, int BLOCK, bool TOPF>
-__global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, FrameParams P, float4* __restrict__ result, DevCounters* ctr,
+// MULTI: _numRays > 1 (the running resultAverage and the ray counter are live path state only then).
+// One launch traces P.n_frames consecutive frames (frame table T): a lane whose path has ended takes its next pixel from the
+// NEXT frame once the current one is handed out, so only the last frame of a launch pays the drain of the long paths.
+template <bool COUNT, int BLOCK, bool TOPF, bool MULTI>
+__global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, FrameParams P, FrameTable T, float4* __restrict__ result, DevCounters* ctr,
                                                unsigned int* __restrict__ next) {
   // LDS of the workgroup: [top of the triangle-BVH forest: top_nodes x 64 B, shared by its waves][stacks of wave 0][wave 1]...
   // The waves of a workgroup share nothing else and never synchronise after this copy.
@@ -816,12 +858,13 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
   int* tl = lds + at * 4 + (threadIdx.x >> 6) * ((P.tlas_stack + P.blas_stack) * 64) + (threadIdx.x & 63);
   int* bl = tl + P.tlas_stack * 64;
   LocalCounters lc;
-  const unsigned int ntiles = (unsigned int)(P.tiles_x * P.n_strips);
+  const unsigned int tiles_per_frame = (unsigned int)(P.tiles_x * P.n_strips);
+  const unsigned int ntiles = tiles_per_frame * (unsigned int)P.n_frames;
   WorkCursor wc; wc.shard = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (kWorkShards - 1u);
   bool exhausted = false;
   int st = ST_DEAD;
   // path state
-  int x = 0, y = 0, ray_i = 0, k = 0;
+  int x = 0, y = 0, ray_i = 0, k = 0, frame = 0;
   float seed = 0;
   v3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), energy = mk3(0, 0, 0), res = mk3(0, 0, 0), avg = mk3(0, 0, 0);
   // trace state (one Trace() in flight per lane)
@@ -850,12 +893,15 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
     // ---- refill dead lanes from the frame's work counter (one atomic per refill): when enough lanes are dead, or when
     // nothing else is left to run ----
     if (!exhausted && nD > 0 && (nD >= P.refill_min || nB + nS + nF == 0)) {
-      if (wave_fetch_pixels(P, mD, st == ST_DEAD, next, ntiles, wc, exhausted, x, y)) {
-        st = ST_FRONT;
-        seed = P.seed; ray_i = 0; k = 0;
-        avg = mk3(0, 0, 0); res = mk3(0, 0, 0); energy = mk3(1, 1, 1);
-        camera_ray<kPOffAfterScene>(P, x, y, seed, o, d);
-      }
+      bool got = wave_fetch_pixels(P, mD, st == ST_DEAD, next, ntiles, wc, exhausted, x, y, tiles_per_frame, &frame);
+      for_each_frame(got, frame, [&](int f, bool mine) {
+        if (mine) {
+          st = ST_FRONT;
+          ray_i = 0; k = 0;
+          avg = mk3(0, 0, 0); res = mk3(0, 0, 0); energy = mk3(1, 1, 1);
+          camera_ray_frame<kTOffAfterParams>(f, P, x, y, true, seed, o, d);
+        }
+      });
       nF = __popcll(__ballot(st == ST_FRONT || st == ST_RESUME));
       nD = __popcll(__ballot(st == ST_DEAD));
     }
@@ -925,23 +971,29 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
       if (mine && cur == kBlasDone) st = (check == 0 && S.n_spheres == 0) ? ST_SHADE : ST_RESUME;
     } else {
       // ---------------- SHADE + bookkeeping of CSMain's loops (RS:444-468) ----------------
+      bool next_ray = false;
       if (st == ST_SHADE) {
         float px = (float)x, py = (float)y;
         bool cont = shade<COUNT>(S, best, o, d, energy, res, seed, px, py, lc);
         k++;
         st = ST_FRONT;
-        if (!cont || k >= P.num_bounces) {
-          avg = avg + res;
-          ray_i++;
-          if (ray_i < P.num_rays) {
-            res = mk3(0, 0, 0); energy = mk3(1, 1, 1); k = 0;
-            camera_ray<kPOffAfterScene>(P, x, y, seed, o, d);
-          } else {
+        if (!cont || k >= P.num_bounces) {                  // RS:453,457-460
+          v3 sum = (MULTI ? avg : mk3(0, 0, 0)) + res;       // RS:464
+          if (MULTI) { avg = sum; ray_i++; next_ray = ray_i < P.num_rays; }
+          if (!next_ray) {
             float n = (float)P.num_rays;
-            st_result(result + (size_t)y * P.width + x, make_float4(avg.x / n, avg.y / n, avg.z / n, 1.0f));
+            st_result(result + (size_t)frame * P.frame_stride + (size_t)y * P.width + x, make_float4(sum.x / n, sum.y / n, sum.z / n, 1.0f));   // RS:468
             st = ST_DEAD;
           }
         }
+      }
+      if (MULTI) {                                          // RS:444: next ray of the pixel, _Seed carries over
+        for_each_frame(next_ray, frame, [&](int f, bool mine) {
+          if (mine) {
+            res = mk3(0, 0, 0); energy = mk3(1, 1, 1); k = 0;
+            camera_ray_frame<kTOffAfterParams>(f, P, x, y, false, seed, o, d);
+          }
+        });
       }
     }
 #ifdef URT_STAMPS
@@ -1340,6 +1392,26 @@ __global__ __launch_bounds__(256) void k_blit_add(const float4* __restrict__ src
   }
 }
 
+// n consecutive blends in one pass (frames of a batched launch): per pixel the SAME operations in the same order as n
+// k_blit_add launches, with 16 (n + 2) bytes of traffic per pixel instead of 48 n.
+struct BlendSamples { float s[kMaxFramesPerLaunch]; };
+__global__ __launch_bounds__(256) void k_blit_add_multi(const float4* __restrict__ src, size_t frame_stride, int n, BlendSamples smp,
+                                                        float4* __restrict__ dst, size_t npix) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (size_t)gridDim.x * blockDim.x) {
+    float4 c = dst[i];
+    for (int f = 0; f < n; f++) {
+      float a = 1.0f / (smp.s[f] + 1.0f);
+      float ia = 1.0f - a;
+      float4 t = src[(size_t)f * frame_stride + i];
+      c.x = t.x * a + c.x * ia;
+      c.y = t.y * a + c.y * ia;
+      c.z = t.z * a + c.z * ia;
+      c.w = a * a + c.w * ia;
+    }
+    dst[i] = c;
+  }
+}
+
 // strips <-> dense buffer (frame-end gather): strip j of this rank = pixel rows (first + j*stride)*8 .. +8
 __global__ __launch_bounds__(256) void k_pack_rows(const float4* __restrict__ img, float4* __restrict__ dense, int width, int height,
                                                    int first_group_row, int row_stride, int n_strips, int to_dense) {
@@ -1440,36 +1512,40 @@ size_t sched_lds_bytes(const DevScene& S, const FrameParams& P) {
   return f4 * 16 + (size_t)(P.tlas_stack + P.blas_stack) * 64 * (size_t)(P.block_threads / 64) * sizeof(int);
 }
 
-template <bool COUNT, int BLOCK, bool TOPF>
-static hipError_t launch_sched_t(const DevScene& S, const FrameParams& P, float4* result, DevCounters* ctr, unsigned int* next,
-                                 int n_blocks, size_t lds, hipStream_t st) {
+template <bool COUNT, int BLOCK, bool TOPF, bool MULTI>
+static hipError_t launch_sched_t(const DevScene& S, const FrameParams& P, const FrameTable& T, float4* result, DevCounters* ctr,
+                                 unsigned int* next, int n_blocks, size_t lds, hipStream_t st) {
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_sched<COUNT, BLOCK, TOPF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)k_sched<COUNT, BLOCK, TOPF, MULTI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((k_sched<COUNT, BLOCK, TOPF>), dim3(n_blocks), dim3(BLOCK), lds, st, S, P, result, ctr, next);
+  hipLaunchKernelGGL((k_sched<COUNT, BLOCK, TOPF, MULTI>), dim3(n_blocks), dim3(BLOCK), lds, st, S, P, T, result, ctr, next);
   return hipGetLastError();
 }
 
 template <bool COUNT, int BLOCK>
-static hipError_t launch_sched_b(const DevScene& S, const FrameParams& P, float4* result, DevCounters* ctr, unsigned int* next,
-                                 int n_blocks, size_t lds, bool top_in_front, hipStream_t st) {
-  return top_in_front ? launch_sched_t<COUNT, BLOCK, true>(S, P, result, ctr, next, n_blocks, lds, st)
-                      : launch_sched_t<COUNT, BLOCK, false>(S, P, result, ctr, next, n_blocks, lds, st);
+static hipError_t launch_sched_b(const DevScene& S, const FrameParams& P, const FrameTable& T, float4* result, DevCounters* ctr,
+                                 unsigned int* next, int n_blocks, size_t lds, bool top_in_front, hipStream_t st) {
+  bool multi = P.num_rays > 1;
+  if (top_in_front) return multi ? launch_sched_t<COUNT, BLOCK, true, true>(S, P, T, result, ctr, next, n_blocks, lds, st)
+                                 : launch_sched_t<COUNT, BLOCK, true, false>(S, P, T, result, ctr, next, n_blocks, lds, st);
+  return multi ? launch_sched_t<COUNT, BLOCK, false, true>(S, P, T, result, ctr, next, n_blocks, lds, st)
+               : launch_sched_t<COUNT, BLOCK, false, false>(S, P, T, result, ctr, next, n_blocks, lds, st);
 }
 
-hipError_t launch_sched(const DevScene& S, const FrameParams& P, float4* result, DevCounters* ctr, unsigned int* next,
-                        int n_blocks, bool top_in_front, bool count, hipStream_t st) {
+hipError_t launch_sched(const DevScene& S, const FrameParams& P, const FrameTable& T, float4* result, DevCounters* ctr,
+                        unsigned int* next, int n_blocks, bool top_in_front, bool count, hipStream_t st) {
   if (n_blocks <= 0) return hipSuccess;
   if (P.block_threads != 64 && P.block_threads != 256) return hipErrorInvalidValue;   // independent waves; a workgroup shares the LDS top-of-tree copy
+  if (P.n_frames < 1 || P.n_frames > kMaxFramesPerLaunch) return hipErrorInvalidValue;
   hipError_t e = hipMemsetAsync(next, 0, kWorkShards * 32 * sizeof(unsigned int), st);
   if (e != hipSuccess) return e;
   size_t lds = sched_lds_bytes(S, P);
   if (P.top_nodes <= 0) top_in_front = false;
-  if (P.block_threads == 64) return count ? launch_sched_b<true, 64>(S, P, result, ctr, next, n_blocks, lds, top_in_front, st)
-                                          : launch_sched_b<false, 64>(S, P, result, ctr, next, n_blocks, lds, top_in_front, st);
-  return count ? launch_sched_b<true, 256>(S, P, result, ctr, next, n_blocks, lds, top_in_front, st)
-               : launch_sched_b<false, 256>(S, P, result, ctr, next, n_blocks, lds, top_in_front, st);
+  if (P.block_threads == 64) return count ? launch_sched_b<true, 64>(S, P, T, result, ctr, next, n_blocks, lds, top_in_front, st)
+                                          : launch_sched_b<false, 64>(S, P, T, result, ctr, next, n_blocks, lds, top_in_front, st);
+  return count ? launch_sched_b<true, 256>(S, P, T, result, ctr, next, n_blocks, lds, top_in_front, st)
+               : launch_sched_b<false, 256>(S, P, T, result, ctr, next, n_blocks, lds, top_in_front, st);
 }
 
 size_t pool_lds_bytes(const FrameParams& P, int k) {
@@ -1511,6 +1587,18 @@ hipError_t launch_blit_add(const float4* src, float4* dst, size_t n_pixels, floa
   size_t nb = (n_pixels + 255) / 256;
   if (nb > 2048) nb = 2048;
   hipLaunchKernelGGL(k_blit_add, dim3((unsigned)nb), dim3(256), 0, st, src, dst, n_pixels, sample);
+  return hipGetLastError();
+}
+
+hipError_t launch_blit_add_multi(const float4* src, size_t frame_stride, int n, const float* samples, float4* dst, size_t n_pixels,
+                                 hipStream_t st) {
+  if (n_pixels == 0 || n <= 0) return hipSuccess;
+  if (n > kMaxFramesPerLaunch) return hipErrorInvalidValue;
+  BlendSamples smp{};
+  for (int f = 0; f < n; f++) smp.s[f] = samples[f];
+  size_t nb = (n_pixels + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(k_blit_add_multi, dim3((unsigned)nb), dim3(256), 0, st, src, frame_stride, n, smp, dst, n_pixels);
   return hipGetLastError();
 }
 

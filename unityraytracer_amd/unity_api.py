@@ -50,6 +50,10 @@ class Context:
     def synchronize(self):
         self.check(self.lib.urt_synchronize(self._h))
 
+    def flush(self):
+        """Submit deferred (batched) frames to the stream without waiting (include/urt.h urt_flush)."""
+        self.check(self.lib.urt_flush(self._h))
+
     def set_stream(self, hip_stream: int | None):
         self.check(self.lib.urt_context_set_stream(self._h, C.c_void_p(hip_stream or 0)))
 
