@@ -151,7 +151,7 @@ typedef struct urt_counters {
   uint32_t watchdog_trips; /* waves that hit a persistent kernel's iteration cap: always 0 unless there is a bug */
   uint64_t launches;      /* trace-kernel launches those dispatches became (< dispatches when frames were batched) */
 } urt_counters;
-/* Options: "frames_per_launch" (0 = auto: own stream -> up to 8 frames / ~16 M pixels per launch, caller's stream -> 1;
+/* Options: "frames_per_launch" (0 = auto: own stream -> up to 16 frames / ~32 M pixels per launch, caller's stream -> 1;
  *                               1 = every dispatch is its own launch; 2..16 = batch that many, also on a caller's stream),
  *          "count_stats" (0/1: per-dispatch traversal counters, slower build of the kernel),
  *          "time_dispatch" (0/1: bracket each dispatch with HIP events, read by urt_get_counters),
@@ -161,7 +161,8 @@ typedef struct urt_counters {
  *                         4 = 3 with a pool of 64 x pool_k paths per wave kept in LDS, experimental),
  *          "block_threads" (64 | 128 | 256: modes 0-2), "xcd_run" (>= 1: run length of the tile order),
  *          "tile_order" (0 bottom-up | 1 top-down), "waves_per_cu" (0 = auto, 1..32), "refill_min" (1..64),
- *          mode 3: "blas_min" / "blas_exit" / "shade_min" (1..64: vote thresholds), "sched_block" (0 auto | 64 | 256),
+ *          mode 3: "blas_min" / "blas_exit" / "shade_min" / "sky_min" (1..64: vote thresholds), "shade_split" (-1 auto | 0 | 1: surface hits and
+ *                  sky misses as separate phases), "sched_block" (0 auto | 64 | 256),
  *                  "top_nodes" (0..256 triangle-BVH nodes kept in LDS), "top_front" (-1 auto | 0 | 1: where that top is
  *                  walked), "lds_tlas" (0/1: small object-level tables in LDS),
  *          mode 4: "pool_k" (1..4), "pool_refill", "pool_blas_min" (1..256), "pool_blas_exit", "pool_inloop",

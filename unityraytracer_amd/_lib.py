@@ -106,7 +106,12 @@ def load():
     }
     assert sorted(protos) == sorted(ABI_SYMBOLS)
     for name, (args, res) in protos.items():
-        fn = getattr(lib, name)
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            if os.environ.get("URT_LIB_PATH"):     # an older build under A/B (scripts/sweep.py --libs): it simply lacks the newer entry points
+                continue
+            raise
         fn.argtypes = args
         fn.restype = res
     _lib = lib

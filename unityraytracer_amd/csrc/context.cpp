@@ -99,11 +99,12 @@ struct urt_context {
   float trace_ms = 0;
 
   int opt_count_stats = 0, opt_time_dispatch = 0, opt_kernel_mode = 3;
-  int opt_block_threads = 64, opt_xcd_run = 1, opt_refill_min = 32, opt_waves_per_cu = 0 /* auto */, opt_blas_min = 28, opt_blas_exit = 6;
+  int opt_block_threads = 64, opt_xcd_run = 1, opt_refill_min = 16, opt_waves_per_cu = 0 /* auto */, opt_blas_min = 28, opt_blas_exit = 14;
   int opt_pool_k = 2, opt_pool_refill = 32, opt_pool_blas_min = 48, opt_pool_blas_exit = 8, opt_pool_inloop = 16, opt_pool_other_min = 24;   // kernel_mode 4
   int opt_sched_block = 0;                  // kernel_mode 3: threads per workgroup (64 or 256; 0 = 256 when there is a BVH top to share)
   int opt_stack_pad = 0;                    // test hook: extra (unused) entries per traversal stack, to reach the > 64 KiB LDS launch path
-  int opt_shade_min = 32;                   // kernel_mode 3
+  int opt_shade_min = 32, opt_sky_min = 32; // kernel_mode 3
+  int opt_shade_split = -1;                 // kernel_mode 3: -1 = auto (= split: measured better or equal on C2-C5), 0 = surface hits and misses shaded in one trip
   int opt_tile_order = 0;                   // persistent modes: order in which the frame's tiles are handed out
   int opt_lds_tlas = 1;                     // kernel_mode 3: object-level heaps, roots and spheres in LDS when small
   int opt_top_front = -1;                   // kernel_mode 3: top-of-forest walk inside the object-level phase (-1 = when the scene has several meshes)
@@ -117,7 +118,7 @@ struct urt_context {
   // per dispatch), the AdditionShader blits that follow the dispatches are deferred with them and run in order after the
   // launch.  Everything else that could observe the images flushes first, so the in-order semantics of RM:806-820
   // stay exactly observable.
-  int opt_frames_per_launch = 0;            // 0 = auto (own stream: up to 8 frames / ~16 M pixels per launch; caller's stream: 1), 1 = off, 2..16
+  int opt_frames_per_launch = 0;            // 0 = auto (own stream: up to 16 frames / ~32 M pixels per launch; caller's stream: 1), 1 = off, 2..16
   uint64_t scene_epoch = 0;                 // bumps at every scene preparation
   struct PostOp { int kind; int frame; urt_handle tex; urt_handle dst; float sample; int first_row, row_stride; void* dense; };   // kind 0 = blit_add(tex@frame -> dst), 1 = pack_rows(tex -> dense)
   struct Pending {
@@ -482,7 +483,7 @@ int batch_limit(urt_context* ctx, const FrameParams& P) {
   if (lim == 0) {
     if (ctx->stream != ctx->own_stream) return 1;        // a caller that shares its stream expects the work ON the stream when dispatch returns
     uint64_t px = (uint64_t)P.tiles_x * 64u * (uint64_t)P.n_strips;
-    lim = (int)std::min<uint64_t>(8, std::max<uint64_t>(1, (16u * 1024u * 1024u + px - 1) / std::max<uint64_t>(1, px)));
+    lim = (int)std::min<uint64_t>(kMaxFramesPerLaunch, std::max<uint64_t>(1, (32u * 1024u * 1024u + px - 1) / std::max<uint64_t>(1, px)));   // 1080p: 16, 2160p: 4
   }
   return std::max(1, std::min(lim, (int)kMaxFramesPerLaunch));
 }
@@ -528,7 +529,7 @@ int do_dispatch(urt_context* ctx, int kernel, int gx, int gy, int gz, int first_
   P.first_group_row = first_row; P.row_stride = row_stride;
   P.n_strips = first_row < group_rows ? (group_rows - first_row + row_stride - 1) / row_stride : 0;
   P.tlas_stack = ctx->tlas_stack; P.blas_stack = ctx->blas_stack + ctx->opt_stack_pad; P.watchdog_steps = ctx->watchdog_steps;
-  P.block_threads = ctx->opt_block_threads; P.xcd_run = ctx->opt_xcd_run; P.tile_order = ctx->opt_tile_order; P.refill_min = ctx->opt_refill_min; P.blas_min = ctx->opt_blas_min; P.blas_exit = ctx->opt_blas_exit; P.shade_min = ctx->opt_shade_min;
+  P.block_threads = ctx->opt_block_threads; P.xcd_run = ctx->opt_xcd_run; P.tile_order = ctx->opt_tile_order; P.refill_min = ctx->opt_refill_min; P.blas_min = ctx->opt_blas_min; P.blas_exit = ctx->opt_blas_exit; P.shade_min = ctx->opt_shade_min; P.sky_min = ctx->opt_sky_min;
   P.n_frames = 1; P.frame_stride = 0;
   if (P.n_strips == 0 || P.tiles_x == 0) return URT_OK;
   if ((uint64_t)P.tiles_x * (uint64_t)P.n_strips * 64u * (uint64_t)kMaxFramesPerLaunch >= 0xffffffffull)
@@ -545,6 +546,7 @@ int do_dispatch(urt_context* ctx, int kernel, int gx, int gy, int gz, int first_
   }
   bool degenerate = P.num_bounces <= 0 || P.num_rays <= 0;      // loops that never run: the megakernel handles them literally
   int mode = degenerate ? 0 : ctx->opt_kernel_mode;
+  if (mode == 3 && P.num_bounces >= (1 << 24)) mode = 2;        // k_sched keeps the bounce index in 24 bits
   bool count = ctx->opt_count_stats != 0;
   const int region[4] = {P.region_w, P.region_h, first_row, row_stride};
   const bool full_cover = P.region_w == res->w && P.region_h == res->h && first_row == 0 && row_stride == 1;
@@ -552,6 +554,7 @@ int do_dispatch(urt_context* ctx, int kernel, int gx, int gy, int gz, int first_
   if (mode == 3) {
     configure_sched(ctx, S, P);
     bool top_in_front = ctx->opt_top_front < 0 ? S.n_meshes > 1 : ctx->opt_top_front != 0;
+    P.shade_split = ctx->opt_shade_split != 0;
     FrameUniforms fu{};
     std::memcpy(fu.c2w, P.c2w, sizeof fu.c2w);
     std::memcpy(fu.invp, P.invp, sizeof fu.invp);
@@ -1052,6 +1055,12 @@ int urt_set_option(urt_context* ctx, const char* name, int value) {
   } else if (std::strcmp(name, "shade_min") == 0) {
     if (value < 1 || value > 64) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "shade_min must be in [1, 64]");
     ctx->opt_shade_min = value;
+  } else if (std::strcmp(name, "shade_split") == 0) {
+    if (value < -1 || value > 1) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "shade_split must be -1 (auto), 0 or 1");
+    ctx->opt_shade_split = value;
+  } else if (std::strcmp(name, "sky_min") == 0) {
+    if (value < 1 || value > 64) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "sky_min must be in [1, 64]");
+    ctx->opt_sky_min = value;
   } else if (std::strcmp(name, "tile_order") == 0) {
     if (value < 0 || value > 1) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "tile_order must be 0 or 1");
     ctx->opt_tile_order = value;

@@ -41,9 +41,11 @@ struct LocalCounters {
 
 struct HitRec {
   float t;     // distance, +inf = miss
-  int kind;    // 0 none, 1 ground plane, 2 sphere, 3 triangle
-  int id;      // sphere index, or leaf-order triangle slot
+  int kid;     // id << 2 | kind;  kind: 0 none, 1 ground plane, 2 sphere, 3 triangle;  id: sphere index, or leaf-order triangle slot
   float u, v;  // barycentrics of a triangle hit
+  __device__ __forceinline__ int kind() const { return kid & 3; }
+  __device__ __forceinline__ int id() const { return (int)((unsigned)kid >> 2); }
+  __device__ __forceinline__ void set(int kind, int id) { kid = (id << 2) | kind; }
 };
 
 __device__ __forceinline__ v3 xyz(float4 q) { return mk3(q.x, q.y, q.z); }
@@ -78,7 +80,7 @@ __device__ __forceinline__ void intersect_sphere(const DevScene& S, int idx, v3 
   if (p2sqr < 0) return;
   float p2 = f_sqrt(p2sqr);
   float t = p1 - p2 > 0 ? p1 - p2 : p1 + p2;
-  if (t > 0 && t < best.t) { best.t = t; best.kind = 2; best.id = idx; }
+  if (t > 0 && t < best.t) { best.t = t; best.set(2, idx); }
 }
 
 // The triangles of one BVH leaf: Moller-Trumbore with back-face culling, RS:199-234 (edge1/edge2 pre-subtracted on
@@ -102,7 +104,7 @@ __device__ __forceinline__ void test_triangle(float4 r0, float4 r1, float4 r2, i
   float t = dot(edge2, qvec) * inv_det;
   int islot = as_int(r0.w);
   bool closer = (t > 0 && t < best.t) || (t > 0 && t == best.t && best_i >= 0 && islot < best_i);
-  if (closer) { best.t = t; best.kind = 3; best.id = slot_in_leaf_order; best.u = u; best.v = v; best_i = islot; }
+  if (closer) { best.t = t; best.set(3, slot_in_leaf_order); best.u = u; best.v = v; best_i = islot; }
 }
 
 // `lds_first` >= 0: the leaf's records are read from `lds_tris` (an LDS copy) starting at triangle lds_first instead of
@@ -231,11 +233,11 @@ __device__ __forceinline__ void intersect_mesh(const DevScene& S, int32_t root, 
 template <bool COUNT>
 __device__ __forceinline__ HitRec trace(const DevScene& S, v3 o, v3 d, int* tl, int* bl, LocalCounters& lc) {
   lc.rays++;
-  HitRec best; best.t = URT_INF; best.kind = 0; best.id = 0; best.u = 0; best.v = 0;
+  HitRec best; best.t = URT_INF; best.kid = 0; best.u = 0; best.v = 0;
   // IntersectGroundPlane RS:156-172
   {
     float t = -o.y / d.y;
-    if (t > 0 && t < best.t) { best.t = t; best.kind = 1; }
+    if (t > 0 && t < best.t) { best.t = t; best.kid = 1; }
   }
   // one reciprocal per axis for the object-level slab test (normative form of RS:282-283)
   v3 rcp = mk3(1.0f / (d.x + kEPSILON), 1.0f / (d.y + kEPSILON), 1.0f / (d.z + kEPSILON));
@@ -328,32 +330,34 @@ __device__ __forceinline__ v3 sample_sky(const DevScene& S, float u, float v) {
 }
 
 // One bounce's shading: result += energy_before * Shade(ray, hit) (A.3); returns any(energy) (RS:457).
+// The two halves of Shade (surface hit RS:388-419, sky miss RS:420-427) are separate functions: the phase-scheduled kernel
+// runs them as separate phases (lanes of one wave that ended on the sky do not sit through the surface code and vice versa).
 template <bool COUNT>
-__device__ __forceinline__ bool shade(const DevScene& S, const HitRec& h, v3& o, v3& d, v3& energy, v3& result,
-                                      float& seed, float px, float py, LocalCounters& lc) {
+__device__ __forceinline__ bool shade_surface(const DevScene& S, const HitRec& h, v3& o, v3& d, v3& energy, v3& result,
+                                              float& seed, float px, float py, LocalCounters& lc) {
   v3 e0 = energy;
   v3 s;
-  if (h.t < URT_INF) {
+  {
     v3 pos = madd(h.t, d, o);
     v3 n, albedo, spec, emission; float smooth;
-    if (h.kind == 1) {                       // RS:164-170
+    if (h.kind() == 1) {                       // RS:164-170
       if (COUNT) lc.hit_ground++;
       n = mk3(0, 1, 0);
       albedo = mk3(0.5f, 0.3f, 0.15f); spec = mk3(0, 0, 0); emission = mk3(0, 0, 0); smooth = 0.3f;
     } else {
       // one material table: spheres first, then mesh objects (an integer select, no pointer select)
       int mat;
-      if (h.kind == 2) {                     // RS:192-194
+      if (h.kind() == 2) {                     // RS:192-194
         if (COUNT) lc.hit_sphere++;
-        n = normalize(pos - xyz(S.sphere_pr[h.id]));
-        mat = h.id;
+        n = normalize(pos - xyz(S.sphere_pr[h.id()]));
+        mat = h.id();
       } else {                               // RS:259-264
         if (COUNT) lc.hit_tri++;
-        const float4* tn = S.tri_norms + 3 * (size_t)h.id;
+        const float4* tn = S.tri_norms + 3 * (size_t)h.id();
         v3 n0 = xyz(tn[0]), n1 = xyz(tn[1]), n2 = xyz(tn[2]);
         float w = 1.0f - h.u - h.v;
         n = normalize((n0 * w) + (n1 * h.u) + (n2 * h.v));
-        mat = S.n_spheres + as_int(S.tri_verts[3 * (size_t)h.id + 1].w);
+        mat = S.n_spheres + as_int(S.tri_verts[3 * (size_t)h.id() + 1].w);
       }
       const float4* m = S.materials + 3 * (size_t)mat;
       float4 m0 = m[0], m1 = m[1], m2 = m[2];
@@ -389,15 +393,28 @@ __device__ __forceinline__ bool shade(const DevScene& S, const HitRec& h, v3& o,
       energy = mk3(0, 0, 0);
     }
     s = emission;
-  } else {
-    if (COUNT) lc.hit_sky++;
-    energy = mk3(0, 0, 0);
-    float theta = f_acos(d.y) / -kPI;
-    float phi = f_atan2(d.x, -d.z) / -kPI * 0.5f;
-    s = sample_sky(S, phi, theta);
   }
   result = result + e0 * s;
   return any_nonzero(energy);
+}
+
+template <bool COUNT>
+__device__ __forceinline__ bool shade_sky(const DevScene& S, v3 d, v3& energy, v3& result, LocalCounters& lc) {
+  v3 e0 = energy;
+  if (COUNT) lc.hit_sky++;
+  energy = mk3(0, 0, 0);
+  float theta = f_acos(d.y) / -kPI;
+  float phi = f_atan2(d.x, -d.z) / -kPI * 0.5f;
+  v3 s = sample_sky(S, phi, theta);
+  result = result + e0 * s;
+  return any_nonzero(energy);                  // false: the path ends here (RS:421,457)
+}
+
+template <bool COUNT>
+__device__ __forceinline__ bool shade(const DevScene& S, const HitRec& h, v3& o, v3& d, v3& energy, v3& result,
+                                      float& seed, float px, float py, LocalCounters& lc) {
+  if (h.t < URT_INF) return shade_surface<COUNT>(S, h, o, d, energy, result, seed, px, py, lc);
+  return shade_sky<COUNT>(S, d, energy, result, lc);
 }
 
 // Cold per-pixel uniforms (the two camera matrices, 128 B) are read from the kernel-argument segment AT USE through a
@@ -719,15 +736,15 @@ struct FrontLds {
   const int32_t* small_first = nullptr;  // [n_meshes] first triangle of MeshObject m in small_tris, or -1
 };
 
-template <bool COUNT, bool TOPF = false>
+template <bool COUNT, bool TOPF = false, bool RAYS = true>
 __device__ __forceinline__ bool trace_front(const DevScene& S, bool fresh, v3 o, v3 d, HitRec& best, int& check, bool& seen,
                                             int* tl, int stride, int32_t& cur, LocalCounters& lc, const FrontLds& L = FrontLds(),
                                             const float4* top = nullptr, int top_nodes = 0, int* bl = nullptr, int* sp_out = nullptr) {
   if (fresh) {
-    lc.rays++;
-    best.t = URT_INF; best.kind = 0; best.id = 0; best.u = 0; best.v = 0;
+    if (RAYS) lc.rays++;                                    // (k_sched counts its rays per wave instead: one register less per lane)
+    best.t = URT_INF; best.kid = 0; best.u = 0; best.v = 0;
     float t = -o.y / d.y;                                   // IntersectGroundPlane RS:156-172
-    if (t > 0 && t < best.t) { best.t = t; best.kind = 1; }
+    if (t > 0 && t < best.t) { best.t = t; best.kid = 1; }
     check = 0; seen = false;
     if (S.n_meshes > 0) { check = 1; tl[0] = 0; }
   }
@@ -809,7 +826,7 @@ __device__ __forceinline__ bool trace_front(const DevScene& S, bool fresh, v3 o,
 // tables.  Per-pixel arithmetic and the order of its operations are exactly those of modes 0-2 (same device
 // functions) — only WHEN and WHERE a lane executes them changes, so pixels are bit-identical.
 // ---------------------------------------------------------------------------------------------------
-enum : int { ST_DEAD = 0, ST_FRONT = 1, ST_RESUME = 2, ST_BLAS = 3, ST_SHADE = 4 };
+enum : int { ST_DEAD = 0, ST_FRONT = 1, ST_RESUME = 2, ST_BLAS = 3, ST_SHADE = 4, ST_SKY = 5 };
 static constexpr unsigned int kWatchdogIters = 1u << 24;    // scheduler trips per wave (a frame needs ~1e3-1e5)
 
 #ifndef URT_SCHED_OCC
@@ -864,14 +881,15 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
   bool exhausted = false;
   int st = ST_DEAD;
   // path state
-  int x = 0, y = 0, ray_i = 0, k = 0, frame = 0;
+  int xy = 0;                                    // pixel: x | y << 16 (both < 65536)
+  int ray_i = 0, kf = 0;                         // kf: bounce index k | frame of the launch << 24
   float seed = 0;
   v3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), energy = mk3(0, 0, 0), res = mk3(0, 0, 0), avg = mk3(0, 0, 0);
   // trace state (one Trace() in flight per lane)
-  HitRec best; best.t = URT_INF; best.kind = 0; best.id = 0; best.u = 0; best.v = 0;
-  int check = 0; bool seen = false;              // object-level heap walk (RS:294-326)
+  HitRec best; best.t = URT_INF; best.kid = 0; best.u = 0; best.v = 0;
+  int cs = 0;                                    // object-level heap walk (RS:294-326): stack height `check` | never-reset `tests` flag << 8
   int32_t cur = kBlasDone; int sp = 0, best_i = -1;   // triangle-BVH cursor of the current MeshObject
-  unsigned int wave_iters = 0;
+  unsigned int wave_iters = 0, wave_rays = 0;
   bool watchdog = false;
 #ifdef URT_STAMPS
   unsigned long long ph_t[4] = {0, 0, 0, 0}, ph_lanes[4] = {0, 0, 0, 0}, ph_trips[4] = {0, 0, 0, 0};   // FRONT, BLAS, SHADE, blas inner trips
@@ -889,15 +907,17 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
     int nD = __popcll(mD);
     int nB = __popcll(__ballot(st == ST_BLAS));
     int nS = __popcll(__ballot(st == ST_SHADE));
+    int nK = __popcll(__ballot(st == ST_SKY));
     int nF = __popcll(__ballot(st == ST_FRONT || st == ST_RESUME));
     // ---- refill dead lanes from the frame's work counter (one atomic per refill): when enough lanes are dead, or when
     // nothing else is left to run ----
-    if (!exhausted && nD > 0 && (nD >= P.refill_min || nB + nS + nF == 0)) {
+    if (!exhausted && nD > 0 && (nD >= P.refill_min || nB + nS + nK + nF == 0)) {
+      int x = 0, y = 0, frame = 0;
       bool got = wave_fetch_pixels(P, mD, st == ST_DEAD, next, ntiles, wc, exhausted, x, y, tiles_per_frame, &frame);
       for_each_frame(got, frame, [&](int f, bool mine) {
         if (mine) {
           st = ST_FRONT;
-          ray_i = 0; k = 0;
+          ray_i = 0; kf = frame << 24; xy = x | (y << 16);
           avg = mk3(0, 0, 0); res = mk3(0, 0, 0); energy = mk3(1, 1, 1);
           camera_ray_frame<kTOffAfterParams>(f, P, x, y, true, seed, o, d);
         }
@@ -909,10 +929,25 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
     if (++wave_iters > kWatchdogIters) { watchdog = true; break; }   // an exit every wave reaches, whatever the data
     int phase;
     int exit_below = 1;              // traversal runs to completion unless other lanes can make progress meanwhile
-    if (nB >= P.blas_min) { phase = ST_BLAS; if (nS + nF > 0 || can_refill) exit_below = min(P.blas_exit, nB); }   // <= nB: the phase always advances a lane
-    else if (nS >= P.shade_min) phase = ST_SHADE;   // SHADE is the longest straight-line code (~1100 VALU whatever the lane count):
-    else if (nF > 0) phase = ST_FRONT;              // a thin batch waits while the cheap FRONT phase can still feed it
-    else if (nS > 0) phase = ST_SHADE;
+    // Surface shading is the longest straight-line code (~750 VALU whatever the lane count, the sky lookup ~270): a thin batch
+    // waits while the FRONT phase can still feed it.  P.shade_split: surface hits and misses are separate phases with their
+    // own thresholds (fuller lanes per trip; pays when FRONT is cheap, i.e. one mesh); otherwise they count together and
+    // run back to back in one trip, so that FRONT — the expensive phase of multi-mesh scenes — gets all of them at once.
+    bool sky_too = false;
+    if (nB >= P.blas_min) { phase = ST_BLAS; if (nS + nK + nF > 0 || can_refill) exit_below = min(P.blas_exit, nB); }   // <= nB: the phase always advances a lane
+    else if (P.shade_split) {
+      if (nS >= P.shade_min) phase = ST_SHADE;
+      else if (nK >= P.sky_min) phase = ST_SKY;
+      else if (nF > 0) phase = ST_FRONT;
+      else if (nS > 0 && nS >= nK) phase = ST_SHADE;
+      else if (nK > 0) phase = ST_SKY;
+      else if (nB > 0) phase = ST_BLAS;
+      else if (exhausted) break;       // every lane dead and no work left
+      else continue;                   // every fetched slot fell outside the region: fetch again
+    }
+    else if (nS + nK >= P.shade_min) { phase = nS > 0 ? ST_SHADE : ST_SKY; sky_too = true; }
+    else if (nF > 0) phase = ST_FRONT;
+    else if (nS + nK > 0) { phase = nS > 0 ? ST_SHADE : ST_SKY; sky_too = true; }
     else if (nB > 0) phase = ST_BLAS;
     else if (exhausted) break;       // every lane dead and no work left
     else continue;                   // every fetched slot fell outside the region: fetch again
@@ -920,18 +955,21 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
 #ifdef URT_STAMPS
     unsigned long long t_ph = wall_clock64();
     int ph_id = phase == ST_FRONT ? 0 : phase == ST_BLAS ? 1 : 2;
-    ph_lanes[ph_id] += (unsigned long long)(phase == ST_FRONT ? nF : phase == ST_BLAS ? nB : nS);
+    ph_lanes[ph_id] += (unsigned long long)(phase == ST_FRONT ? nF : phase == ST_BLAS ? nB : phase == ST_SHADE ? nS : nK);
     ph_trips[ph_id]++;
     if (exhausted) { if (!dr_live) dr_live = 64 - nD; dr_trips[ph_id]++; }
 #endif
     if (phase == ST_FRONT) {
       // ---------------- FRONT / RESUME: Trace() up to the next triangle-BVH visit (RS:364-383) ----------------
+      wave_rays += (unsigned int)__popcll(__ballot(st == ST_FRONT));     // Trace() invocations (RS:454), counted per wave
       if (st == ST_FRONT || st == ST_RESUME) {
         sp = 0;
-        bool need = TOPF ? trace_front<COUNT, true>(S, st == ST_FRONT, o, d, best, check, seen, tl, 64, cur, lc, L, top, P.top_nodes, bl, &sp)
-                         : trace_front<COUNT>(S, st == ST_FRONT, o, d, best, check, seen, tl, 64, cur, lc, L);
+        int check = cs & 0xff; bool seen = (cs >> 8) != 0;
+        bool need = TOPF ? trace_front<COUNT, true, false>(S, st == ST_FRONT, o, d, best, check, seen, tl, 64, cur, lc, L, top, P.top_nodes, bl, &sp)
+                         : trace_front<COUNT, false, false>(S, st == ST_FRONT, o, d, best, check, seen, tl, 64, cur, lc, L);
+        cs = check | (seen ? 256 : 0);
         if (need) { best_i = -1; st = ST_BLAS; }
-        else st = ST_SHADE;
+        else st = best.t < URT_INF ? ST_SHADE : ST_SKY;
       }
     } else if (phase == ST_BLAS) {
       // ---------------- BLAS: triangle BVH of one MeshObject, resumable ----------------
@@ -968,30 +1006,36 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
       }
       // back to the heap walk (RS:323-325 continues) — or, when nothing of Trace() is left to do (empty object-level stack and
       // no spheres), straight to shading: saves the path one scheduling round trip per bounce
-      if (mine && cur == kBlasDone) st = (check == 0 && S.n_spheres == 0) ? ST_SHADE : ST_RESUME;
+      if (mine && cur == kBlasDone) st = ((cs & 0xff) == 0 && S.n_spheres == 0) ? (best.t < URT_INF ? ST_SHADE : ST_SKY) : ST_RESUME;
     } else {
       // ---------------- SHADE + bookkeeping of CSMain's loops (RS:444-468) ----------------
       bool next_ray = false;
-      if (st == ST_SHADE) {
-        float px = (float)x, py = (float)y;
-        bool cont = shade<COUNT>(S, best, o, d, energy, res, seed, px, py, lc);
-        k++;
+      bool cont = false, shaded = false;
+      if (phase == ST_SHADE) {                              // surface hits
+        if (st == ST_SHADE) { shaded = true; cont = shade_surface<COUNT>(S, best, o, d, energy, res, seed, (float)(xy & 0xffff), (float)((unsigned)xy >> 16), lc); }
+      }
+      if (phase == ST_SKY || (sky_too && nK > 0)) {         // misses
+        if (st == ST_SKY) { shaded = true; cont = shade_sky<COUNT>(S, d, energy, res, lc); }
+      }
+      if (shaded) {
+        kf++;
         st = ST_FRONT;
-        if (!cont || k >= P.num_bounces) {                  // RS:453,457-460
+        if (!cont || (kf & 0xffffff) >= P.num_bounces) {    // RS:453,457-460
           v3 sum = (MULTI ? avg : mk3(0, 0, 0)) + res;       // RS:464
           if (MULTI) { avg = sum; ray_i++; next_ray = ray_i < P.num_rays; }
           if (!next_ray) {
             float n = (float)P.num_rays;
-            st_result(result + (size_t)frame * P.frame_stride + (size_t)y * P.width + x, make_float4(sum.x / n, sum.y / n, sum.z / n, 1.0f));   // RS:468
+            st_result(result + (size_t)((unsigned)kf >> 24) * P.frame_stride + (size_t)((unsigned)xy >> 16) * P.width + (xy & 0xffff),
+                      make_float4(sum.x / n, sum.y / n, sum.z / n, 1.0f));   // RS:468
             st = ST_DEAD;
           }
         }
       }
       if (MULTI) {                                          // RS:444: next ray of the pixel, _Seed carries over
-        for_each_frame(next_ray, frame, [&](int f, bool mine) {
+        for_each_frame(next_ray, (int)((unsigned)kf >> 24), [&](int f, bool mine) {
           if (mine) {
-            res = mk3(0, 0, 0); energy = mk3(1, 1, 1); k = 0;
-            camera_ray_frame<kTOffAfterParams>(f, P, x, y, false, seed, o, d);
+            res = mk3(0, 0, 0); energy = mk3(1, 1, 1); kf &= (int)0xff000000;
+            camera_ray_frame<kTOffAfterParams>(f, P, xy & 0xffff, (int)((unsigned)xy >> 16), false, seed, o, d);
           }
         });
       }
@@ -1013,6 +1057,7 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
   }
 #endif
   if (watchdog && (threadIdx.x & 63) == 0) atomicAdd(&ctr->watchdog, 1ull);
+  lc.rays = (threadIdx.x & 63) == 0 ? wave_rays : 0u;
   flush_counters<COUNT>(lc, ctr);
 }
 
@@ -1158,16 +1203,16 @@ __global__ __launch_bounds__(64) void k_pool(DevScene S, FrameParams P, float4* 
       if (mine >= 0) {
         bool fresh = stt[mine] == PS_FRONT;
         v3 o = mk3(PFf(F_OX, mine), PFf(F_OY, mine), PFf(F_OZ, mine)), d = mk3(PFf(F_DX, mine), PFf(F_DY, mine), PFf(F_DZ, mine));
-        HitRec best; best.t = URT_INF; best.kind = 0; best.id = 0; best.u = 0; best.v = 0;
+        HitRec best; best.t = URT_INF; best.kid = 0; best.u = 0; best.v = 0;
         int check = 0; bool seen = false;
         if (!fresh) {
           int ki = PF(F_KINDID, mine), cs = PF(F_CHECK, mine);
-          best.t = PFf(F_T, mine); best.kind = ki & 7; best.id = ki >> 3; best.u = PFf(F_U, mine); best.v = PFf(F_V, mine);
+          best.t = PFf(F_T, mine); best.kid = ki; best.u = PFf(F_U, mine); best.v = PFf(F_V, mine);
           check = cs >> 1; seen = (cs & 1) != 0;
         }
         int32_t cur = kBlasDone;
         bool need = trace_front<COUNT>(S, fresh, o, d, best, check, seen, tls + mine, NP, cur, lc);
-        PFset(F_T, mine, best.t); PF(F_KINDID, mine) = (best.id << 3) | best.kind; PFset(F_U, mine, best.u); PFset(F_V, mine, best.v);
+        PFset(F_T, mine, best.t); PF(F_KINDID, mine) = best.kid; PFset(F_U, mine, best.u); PFset(F_V, mine, best.v);
         PF(F_CHECK, mine) = (check << 1) | (seen ? 1 : 0);
         if (need) { PF(F_CUR, mine) = cur; PF(F_SP, mine) = 0; PF(F_BESTI, mine) = -1; stt[mine] = PS_BLAS; }
         else stt[mine] = PS_SHADE;
@@ -1181,7 +1226,7 @@ __global__ __launch_bounds__(64) void k_pool(DevScene S, FrameParams P, float4* 
       const int n0 = min(64, nB);
       const int exit_below = (nShade + nFront > 0 || can_fetch) ? min(P.blas_exit, n0) : 1;
       v3 o = mk3(0, 0, 0), d = mk3(0, 0, 1);
-      HitRec best; best.t = URT_INF; best.kind = 0; best.id = 0; best.u = 0; best.v = 0;
+      HitRec best; best.t = URT_INF; best.kid = 0; best.u = 0; best.v = 0;
       int32_t cur = kBlasDone; int sp = 0, best_i = -1;
       bool load = mys >= 0, first = true;
       BlasRay R = blas_ray(o, d);
@@ -1200,7 +1245,7 @@ __global__ __launch_bounds__(64) void k_pool(DevScene S, FrameParams P, float4* 
         if (load) {
           int ki = PF(F_KINDID, mys);
           o = mk3(PFf(F_OX, mys), PFf(F_OY, mys), PFf(F_OZ, mys)); d = mk3(PFf(F_DX, mys), PFf(F_DY, mys), PFf(F_DZ, mys));
-          best.t = PFf(F_T, mys); best.kind = ki & 7; best.id = ki >> 3; best.u = PFf(F_U, mys); best.v = PFf(F_V, mys);
+          best.t = PFf(F_T, mys); best.kid = ki; best.u = PFf(F_U, mys); best.v = PFf(F_V, mys);
           cur = PF(F_CUR, mys); sp = PF(F_SP, mys); best_i = PF(F_BESTI, mys);
           R = blas_ray(o, d);
           load = false;
@@ -1223,14 +1268,14 @@ __global__ __launch_bounds__(64) void k_pool(DevScene S, FrameParams P, float4* 
           cur = blas_pop(bl, sp);
         }
         if (active && cur == kBlasDone) {                              // ray finished: back to the object-level walk (RS:323-325)
-          PFset(F_T, mys, best.t); PF(F_KINDID, mys) = (best.id << 3) | best.kind; PFset(F_U, mys, best.u); PFset(F_V, mys, best.v);
+          PFset(F_T, mys, best.t); PF(F_KINDID, mys) = best.kid; PFset(F_U, mys, best.u); PFset(F_V, mys, best.v);
           stt[mys] = ((PF(F_CHECK, mys) >> 1) == 0 && S.n_spheres == 0) ? PS_SHADE : PS_RESUME;   // nothing of Trace() left: shade next
           pin[lane] = -1;
           mys = -1;
         }
       }
       if (mys >= 0) {                                                  // yield: the traversal stays pinned to this lane
-        PFset(F_T, mys, best.t); PF(F_KINDID, mys) = (best.id << 3) | best.kind; PFset(F_U, mys, best.u); PFset(F_V, mys, best.v);
+        PFset(F_T, mys, best.t); PF(F_KINDID, mys) = best.kid; PFset(F_U, mys, best.u); PFset(F_V, mys, best.v);
         PF(F_CUR, mys) = cur; PF(F_SP, mys) = sp; PF(F_BESTI, mys) = best_i;
         stt[mys] = PS_PINNED;
         pin[lane] = mys;
@@ -1245,7 +1290,7 @@ __global__ __launch_bounds__(64) void k_pool(DevScene S, FrameParams P, float4* 
         float px = (float)x, py = (float)y, seed = PFf(F_SEED, mine);
         v3 o = mk3(PFf(F_OX, mine), PFf(F_OY, mine), PFf(F_OZ, mine)), d = mk3(PFf(F_DX, mine), PFf(F_DY, mine), PFf(F_DZ, mine));
         v3 energy = mk3(PFf(F_EX, mine), PFf(F_EY, mine), PFf(F_EZ, mine)), res = mk3(PFf(F_RX, mine), PFf(F_RY, mine), PFf(F_RZ, mine));
-        HitRec best; best.t = PFf(F_T, mine); best.kind = ki & 7; best.id = ki >> 3; best.u = PFf(F_U, mine); best.v = PFf(F_V, mine);
+        HitRec best; best.t = PFf(F_T, mine); best.kid = ki; best.u = PFf(F_U, mine); best.v = PFf(F_V, mine);
         bool cont = shade<COUNT>(S, best, o, d, energy, res, seed, px, py, lc);
         k++;
         int nst = PS_FRONT;

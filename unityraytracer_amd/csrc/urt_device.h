@@ -58,7 +58,9 @@ struct FrameParams {
   int xcd_run;              // blocks per XCD run in the tile order (kernels.hip tile_pixel)
   int refill_min;           // persistent modes: dead lanes per wave that trigger a refill (1..64)
   int blas_min;             // mode 3: lanes parked in BLAS before the traversal phase is scheduled (1..64)
-  int shade_min;            // mode 3: SHADE lanes that make the phase run ahead of FRONT (1..64)
+  int shade_min;            // mode 3: SHADE (surface-hit) lanes that make the phase run ahead of FRONT (1..64)
+  int sky_min;              // mode 3: SKY (miss) lanes that make the sky-lookup phase run ahead of FRONT (1..64)
+  int shade_split;          // mode 3: surface hits and misses are scheduled as separate phases (0/1)
   int blas_exit;            // mode 3: the traversal phase yields when fewer lanes than this are still traversing (1..64)
   int top_nodes;            // mode 3: triangle-BVH nodes [0, top_nodes) are copied to LDS (breadth-first top of the forest); 0 = none
   int lds_small;            // mode 3: triangle records of the single-leaf MeshObjects in LDS (needs lds_mesh) (0/1)
