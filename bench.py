@@ -67,7 +67,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="C3", help="BASELINE.json config to trace (C2..C5); the metric is quoted on C3")
+    ap.add_argument("--config", default="C3", help="BASELINE.json config to trace (C2..C5, C3D = C3 in close-up); the metric is quoted on C3")
     ap.add_argument("--kernel-mode", type=int, default=None, help="0 per-pixel, 1 per-bounce queues, 2 persistent, 3 persistent + phase-scheduled lanes (default)")
     ap.add_argument("--frames-per-launch", type=int, default=None, help="library option frames_per_launch (0 auto, 1 = one launch per frame, 2..16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -102,8 +102,8 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     # ---- workload --------------------------------------------------------------------------------
-    base_w, base_h = (1920, 1080) if args.config in ("C2", "C3") else (3840, 2160)
-    s = math.sqrt(world) if args.config in ("C2", "C3") else math.sqrt(world / 8.0) if world > 1 else 1.0
+    base_w, base_h = (1920, 1080) if args.config in ("C2", "C3", "C3D") else (3840, 2160)
+    s = math.sqrt(world) if args.config in ("C2", "C3", "C3D") else math.sqrt(world / 8.0) if world > 1 else 1.0
     width, height = int(round(base_w * s)), int(round(base_h * s))
     scene = scenes.CONFIGS[args.config](width, height)
 
@@ -246,8 +246,8 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")       # written from rocprofv3 --pmc passes (profiles/README.md)
         if os.path.exists(pmc):
             try:
-                j = json.load(open(pmc))
-                if j.get("config") == args.config and world == 1 and abs(j.get("frames_per_launch", 1) - frames_per_launch) < 0.51:
+                j = json.load(open(pmc)).get("configs", {}).get(args.config)
+                if j and world == 1 and abs((j.get("frames_per_launch") or 1) - frames_per_launch) < 0.51:
                     traffic = j.get("hbm_bytes_per_launch")
                     traffic_source = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command, not this run)"
             except Exception:

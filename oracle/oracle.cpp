@@ -83,6 +83,8 @@ static inline RayTraceParams ldparams(const urt_RayTraceParams& p) {
   return r;
 }
 
+static int g_literal_division = 0;      // test-only variant switch, see Tracer::IntersectBVHNode
+
 struct Tracer {
   const OracleScene& S;
   int mode;
@@ -283,6 +285,8 @@ struct Tracer {
 
   // RS:271-291.  Normative evaluation: one reciprocal per axis, (bound - origin) * rcp — see
   // DESIGN.md "normative arithmetic" (D3D `div` is itself specified to 1 ulp).
+  // g_literal_division (a test-only switch, oracle_set_literal_division): evaluate RS:282-283 with the two divisions
+  // written there instead — tests/test_oracle_variants.py counts the pixels that choice moves.
   static bool IntersectBVHNode(const Ray& ray, const urt_BVHNode& node) {
     if (node.vmin[0] == node.vmax[0] && node.vmin[1] == node.vmax[1] && node.vmin[2] == node.vmax[2]) return false;
     float t_min = -kFLOAT_MAX;
@@ -290,9 +294,17 @@ struct Tracer {
     const float o[3] = {ray.origin.x, ray.origin.y, ray.origin.z};
     const float d[3] = {ray.direction.x, ray.direction.y, ray.direction.z};
     for (int i = 0; i < 3; i++) {
+      float t1, t2;
+      if (g_literal_division) {
+        t1 = (node.vmin[i] - o[i]) / (d[i] + kEPSILON);
+        t2 = (node.vmax[i] - o[i]) / (d[i] + kEPSILON);
+        t_min = f_max(t_min, f_min(t1, t2));
+        t_max = f_min(t_max, f_max(t1, t2));
+        continue;
+      }
       float rcp = 1.0f / (d[i] + kEPSILON);
-      float t1 = (node.vmin[i] - o[i]) * rcp;
-      float t2 = (node.vmax[i] - o[i]) * rcp;
+      t1 = (node.vmin[i] - o[i]) * rcp;
+      t2 = (node.vmax[i] - o[i]) * rcp;
       t_min = f_max(t_min, f_min(t1, t2));
       t_max = f_min(t_max, f_max(t1, t2));
     }
@@ -700,6 +712,10 @@ void oracle_sphere_leaf_bounds(const urt_Sphere* spheres, int n_spheres, urt_BVH
     out[i].index = i;
   }
 }
+
+// Test-only: 1 = the object-level slab test divides twice per axis exactly as RS:282-283 is written; 0 = the normative
+// one-reciprocal form.  Process-wide; callers set it back.
+void oracle_set_literal_division(int on) { g_literal_division = on ? 1 : 0; }
 
 int oracle_hardware_threads(void) { return (int)std::thread::hardware_concurrency(); }
 

@@ -77,6 +77,8 @@ def load(build: bool = True):
     lib.oracle_mesh_leaf_bounds.restype = None
     lib.oracle_sphere_leaf_bounds.argtypes = [vp, i, vp]
     lib.oracle_sphere_leaf_bounds.restype = None
+    lib.oracle_set_literal_division.argtypes = [i]
+    lib.oracle_set_literal_division.restype = None
     lib.oracle_hardware_threads.argtypes = []
     lib.oracle_hardware_threads.restype = i
     _lib = lib
@@ -204,6 +206,12 @@ def probe_aabb(origin, direction, vmin, vmax, index=-1):
     node = np.zeros(1, dtype=BVHNODE_DT)
     node["vmin"], node["vmax"], node["index"] = vmin, vmax, index
     return bool(lib.oracle_probe_aabb(_ptr(ray), _ptr(node)))
+
+
+def set_literal_division(on: bool):
+    """Test-only variant: the object-level slab test (RS:282-283) with its two literal divisions per axis instead of the
+    normative one-reciprocal form.  Process-wide; set it back to False afterwards."""
+    load().oracle_set_literal_division(1 if on else 0)
 
 
 def hardware_threads() -> int:

@@ -1,10 +1,13 @@
-"""Reduce gpurun_out/prof (scripts/collect_profiles.sh) to the small files kept under profiles/:
-   <prefix>_kernel_stats.csv, <prefix>_pmc.json, pmc_traffic.json, <prefix>_bench.json.log."""
+"""Reduce gpurun_out/prof_<CONFIG> (scripts/collect_profiles.sh) to the small files kept under profiles/:
+   <prefix>_kernel_stats.csv, <prefix>_pmc_k_sched.json, <prefix>_bench.json.log, and the config's entry of pmc_traffic.json.
+   usage: python scripts/reduce_profiles.py CONFIG [round-prefix, default r02]"""
 import csv, glob, json, os, shutil, sys
-src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof"
-prefix = sys.argv[2] if len(sys.argv) > 2 else "r01_bench_c3"
+cfg = sys.argv[1] if len(sys.argv) > 1 else "C3"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
+src = f"gpurun_out/prof_{cfg}"
+prefix = f"{rnd}_bench_{cfg.lower()}"
 dst = "profiles"
-KERNEL = "k_sched<false"   # the timed trace kernel (counting replay is k_sched<true ...)
+KERNEL = "k_sched<false"   # the timed trace kernel (the counting replay is k_sched<true ...)
 
 def newest(pattern):
     """one file per pass directory: gpurun merges new results next to older ones"""
@@ -14,11 +17,20 @@ def newest(pattern):
         if d not in by_dir or os.path.getmtime(f) > os.path.getmtime(by_dir[d]): by_dir[d] = f
     return sorted(by_dir.values())
 
+bench = {}
+b = os.path.join(src, "bench.json.log")
+if os.path.exists(b):
+    shutil.copy(b, os.path.join(dst, f"{prefix}_n1.json.log"))
+    try: bench = json.loads(open(b).read().strip().splitlines()[-1])
+    except Exception: bench = {}
 stats = sorted(glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime, reverse=True)
+kname, avg_ns, calls = None, None, None
 if stats:
     shutil.copy(stats[0], os.path.join(dst, f"{prefix}_kernel_stats.csv"))
     for r in csv.DictReader(open(stats[0])):
-        if KERNEL in r["Name"]: print("kernel stats:", r["Name"][:60], "calls", r["Calls"], "avg ns", r["AverageNs"])
+        if KERNEL in r["Name"]:
+            kname, avg_ns, calls = r["Name"], float(r["AverageNs"]), int(r["Calls"])
+            print("kernel stats:", r["Name"][:70], "calls", r["Calls"], "avg ns", r["AverageNs"])
 pmc = {}
 for f in newest(os.path.join(src, "pmc_*", "**", "*counter_collection.csv")):
     acc = {}
@@ -26,17 +38,22 @@ for f in newest(os.path.join(src, "pmc_*", "**", "*counter_collection.csv")):
         if KERNEL not in r["Kernel_Name"]: continue
         acc.setdefault(r["Counter_Name"], {}).setdefault(r["Dispatch_Id"], 0.0)
         acc[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
-    for k, per in acc.items(): pmc[k] = sum(per.values()) / len(per)
+    for k, per in acc.items(): pmc[k] = sum(per.values()) / len(per)      # average per LAUNCH
 json.dump(pmc, open(os.path.join(dst, f"{prefix}_pmc_k_sched.json"), "w"), indent=1, sort_keys=True)
 print(json.dumps(pmc, indent=1, sort_keys=True))
 if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
     hbm = int(2 * pmc["FETCH_SIZE"] * 1024 + pmc["WRITE_SIZE"] * 1024)
-    json.dump({"config": "C3", "kernel": "k_sched<false, 256, false>", "round": 1, "FETCH_SIZE_KB_per_launch": pmc["FETCH_SIZE"],
-               "WRITE_SIZE_KB_per_launch": pmc["WRITE_SIZE"],
-               "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request -> doubled (MI355X_MICROARCH.md 'HBM'); WRITE_SIZE exact",
-               "hbm_bytes_per_launch": hbm,
-               "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline"},
-              open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+    path = os.path.join(dst, "pmc_traffic.json")
+    try: allcfg = json.load(open(path))
+    except Exception: allcfg = {}
+    if "configs" not in allcfg: allcfg = {"configs": {}}
+    rl = bench.get("roofline") or {}
+    allcfg["configs"][cfg] = {
+        "kernel": kname, "round": rnd, "frames_per_launch": rl.get("frames_per_launch"),
+        "FETCH_SIZE_KB_per_launch": pmc["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": pmc["WRITE_SIZE"],
+        "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request -> doubled (MI355X_MICROARCH.md 'HBM'); WRITE_SIZE exact",
+        "hbm_bytes_per_launch": hbm, "rocprof_avg_launch_ms": None if avg_ns is None else avg_ns / 1e6, "rocprof_launches": calls,
+        "bench_launch_ms": rl.get("launch_ms"), "algorithmic_bytes_per_launch": rl.get("algorithmic_bytes_per_launch"), "frac": rl.get("frac"),
+        "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --config {cfg} --steps 20 --warmup 5 --no-cpu-baseline; averages over the launches of the run"}
+    json.dump(allcfg, open(path, "w"), indent=1)
     print("hbm bytes per launch", hbm)
-b = os.path.join(src, "bench.json.log")
-if os.path.exists(b): shutil.copy(b, os.path.join(dst, f"{prefix}_n1.json.log"))

@@ -431,6 +431,16 @@ def config3(width=1920, height=1080, slices=200, stacks=175, sky=None) -> Scene:
                  sky=sky if sky is not None else make_sky())
 
 
+def config3_dense(width=1920, height=1080, sky=None) -> Scene:
+    """C3D: the C3 mesh in close-up (camera at (0, 2.4, -7.3), 0.8 units in front of the mesh's bounding box): every primary
+    ray enters the triangle BVH and about half of them end on a triangle — the frame on which "during BVH traversal" can
+    be measured.  Same mesh, sky, bounces and resolution as C3."""
+    sc = config3(width, height, sky=sky)
+    sc = sc.resized(width, height, position=(0.0, 2.4, -7.3))
+    sc.name = sc.name.replace("C3-", "C3D-closeup-")
+    return sc
+
+
 def _cornell(b: MeshSceneBuilder, half=5.0, height=10.0, zc=0.0):
     x0, x1, y0, y1, z0, z1 = -half, half, 0.002, height, zc - half, zc + half
     white = _params((0.73, 0.73, 0.73), (0, 0, 0), (0, 0, 0), 0.1)
@@ -525,4 +535,4 @@ def many_meshes_scene(width=128, height=80, n=300, level=0, sky=None) -> Scene:
                  sky=sky if sky is not None else make_sky(128, 64))
 
 
-CONFIGS = {"C1": config1, "C2": config2, "C3": config3, "C4": config4, "C5": config5}
+CONFIGS = {"C1": config1, "C2": config2, "C3": config3, "C4": config4, "C5": config5, "C3D": config3_dense}
