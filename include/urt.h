@@ -204,6 +204,24 @@ URT_API int urt_host_write_pfm(const char* path, const float* rgba, int width, i
 URT_API int urt_host_write_png(const char* path, const float* rgba, int width, int height);
 URT_API const char* urt_host_io_last_error(void);
 
+/* ---- host-side debug log and BVH inspection (no GPU needed) ------------------ */
+/* RayTraceDebug.Log (RD:25-36): appends `text` + newline to the file when level <= debug_level.  Returns URT_OK when
+ * written, 1 when filtered by the level (the reference's Log returns 1 then as well). */
+URT_API int urt_host_log(const char* path, int debug_level, int level, const char* text);
+/* The five count lines of RebuildObjectLists (RM:331-335): "# of Spheres: n", "# of Mesh Objects: n", ... at level 2. */
+URT_API int urt_host_log_scene_counts(const char* path, int debug_level, int n_spheres, int n_mesh_objects, int n_vertices,
+                                      int n_indices, int n_normals);
+/* The two reports of RebuildTrees (RM:731-735): amount, depth, complete length 2^depth - 1, real length — at level 2. */
+URT_API int urt_host_log_tree_report(const char* path, int debug_level, int n_mesh_objects, int mesh_depth, int mesh_real_length,
+                                     int n_spheres, int sphere_depth, int sphere_real_length);
+/* Text stand-in for the editor gizmos of RayTraceDebug.DrawBVH (RD:92-117): walks `depth` levels of the implicit heap from the
+ * root (children 2i+1 / 2i+2, pre-order) and writes one line per node: "(position in list, object index)" as the gizmo labels
+ * it (RD:108), the box, its centre, and " [ray]" when the test segment start -> end passes RD's CPU slab test (RD:70-89; the
+ * gizmo paints those boxes black).  ray_start3 / ray_end3 may both be NULL.  out_lines = nodes written. */
+URT_API int urt_host_dump_bvh(const char* path, const urt_BVHNode* nodes, int n_nodes, int depth, const float* ray_start3,
+                              const float* ray_end3, int* out_lines);
+URT_API const char* urt_host_debug_last_error(void);
+
 /* ---- introspection for tests (host only, no GPU needed) ------------------------------------ */
 /* Run the library's triangle-BVH builder — the one urt_shader_dispatch uses — over host copies of
  * _MeshObjects (112 B records), _Vertices, _Indices, and keep the result in a process-wide cache.

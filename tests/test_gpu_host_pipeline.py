@@ -1,0 +1,158 @@
+"""GPU: the rows either side of the hot path driven end to end through the HIP kernels.
+
+f1/f2  a scene built the reference's way — RegisterObject -> RebuildObjectLists (C++ ComputeNormals RM:340-368 and the
+       C++ object-level heaps RM:405-722) -> RebuildTrees -> frames — must give the same pixels on the GPU as the oracle
+       gives on those very lists, with the literal (quirky, A.7) leaf boxes as well as the tight ones;
+f3     a Radiance .hdr file on disk -> urt_host_load_hdr -> `_SkyboxTexture` (RM:776): HIP == oracle on the loaded texels;
+f4     the screenshot of a GPU frame (RM:762) is byte-identical to the screenshot of the oracle's frame, and the debug log /
+       BVH dump carry the reference's counts (RM:331-335, 731-735; RD:92-117)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle
+from unityraytracer_amd import RayTraceDebug, RayTraceMaster, RayTraceObject, debug_build_blas, host_io, scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def bits_equal(a, b):
+    return np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def registered_scene(width=160, height=96):
+    """Objects as RayTraceObject.cs hands them over: two spheres, a displaced blob, a rotated cube-ish icosphere and a quad —
+    the quad and the blob share welded positions so that ComputeNormals' cross-mesh weld (RM:345-364) matters."""
+    objs = []
+    objs.append(RayTraceObject(type=1, position=(-2.5, 1.0, 1.0), radius=1.0, albedoColor=(0.1, 0.1, 0.1), specularColor=(0.8, 0.8, 0.8), smoothness=0.9))
+    objs.append(RayTraceObject(type=1, position=(2.8, 0.6, -1.0), radius=0.6, albedoColor=(0.8, 0.2, 0.2), specularColor=(0.05, 0.05, 0.05), emissionColor=(0.4, 0.3, 0.1), smoothness=0.2))
+    v, t = scenes.uv_blob(18, 13)
+    objs.append(RayTraceObject(vertices=v, triangles=t, localToWorldMatrix=scenes.trs(translate=(0.0, 1.2, 0.5), scale=1.3, yaw_deg=25.0),
+                               albedoColor=(0.7, 0.6, 0.3), specularColor=(0.2, 0.2, 0.2), smoothness=0.5))
+    v2, t2 = scenes.icosphere(1, bumps=0.15)
+    objs.append(RayTraceObject(vertices=v2, triangles=t2, localToWorldMatrix=scenes.trs(translate=(-1.0, 0.7, -2.5), scale=(0.7, 0.5, 0.9), yaw_deg=-40.0),
+                               albedoColor=(0.2, 0.7, 0.4), specularColor=(0.3, 0.3, 0.3), smoothness=0.7))
+    vq, tq = scenes.quad((-1.5, 0.0, 0.0), (1.5, 0.0, 0.0), (1.5, 2.0, 0.0), (-1.5, 2.0, 0.0))
+    objs.append(RayTraceObject(vertices=vq, triangles=tq, localToWorldMatrix=scenes.trs(translate=(0.5, 0.05, 4.0), yaw_deg=180.0),
+                               albedoColor=(0.9, 0.9, 0.9), specularColor=(0.0, 0.0, 0.0), emissionColor=(1.5, 1.5, 1.2), smoothness=0.0))
+    sc = scenes.Scene("registered", width, height, 5, 2, sky=scenes.make_sky(128, 64))
+    return sc, objs
+
+
+@pytest.mark.parametrize("literal", [False, True])
+def test_registered_objects_through_cpp_flattening_render_like_the_oracle(gpu_ctx, tmp_path, literal):
+    sc, objs = registered_scene()
+    m = RayTraceMaster(gpu_ctx, sc)
+    m.rayDebug = RayTraceDebug(str(tmp_path), "log", 2)
+    for o in objs:
+        m.RegisterObject(o)                                        # RO:42 -> RM:215-221
+    assert m._treesNeedRebuilding
+    # OnRenderImage's rebuild branch (RM:850-859) with the literal / tight leaf boxes
+    m._currentSample = 0
+    m._treesNeedRebuilding = False
+    m.RebuildObjectLists(literal_leaf_bounds=literal)
+    m.RebuildTrees()
+    for _ in range(3):
+        m.OnRenderImage()
+    got_t, got_c = m._target.GetPixels(), m._converged.GetPixels()
+    # the oracle on the very lists RebuildObjectLists produced (sc was filled in place)
+    assert len(sc.spheres) == 2 and len(sc.mesh_objects) == 3 and len(sc.normals) == len(sc.vertices)
+    o = pyoracle.Oracle(sc)
+    nodes, tri, root, _, _ = debug_build_blas(sc.mesh_objects, sc.vertices, sc.indices)
+    o.set_blas(nodes, tri, root)
+    acc = np.zeros((sc.height, sc.width, 4), np.float32)
+    for i in range(3):
+        ox, oy, sd = scenes.frame_uniforms(i)
+        o.set_frame((ox, oy), sd)
+        img = o.render(mode=1, threads=8)
+        acc = pyoracle.accumulate(img, acc, i)
+    assert bits_equal(got_t, img) and bits_equal(got_c, acc)
+    # brute force (RS:243-266) agrees too on these lists
+    assert bits_equal(o.render(mode=0, threads=8), img)
+    # the counts the reference logs (RM:331-335, 731-735)
+    log = open(os.path.join(str(tmp_path), "log.txt")).read()
+    for line in ("# of Spheres: 2", "# of Mesh Objects: 3", f"# of Vertices: {len(sc.vertices)}", f"# of Indices: {len(sc.indices)}",
+                 f"# of Normals: {len(sc.normals)}", "[MESH OBJECTS] \n > Amount: 3\n > Depth: 3\n > Complete Length: 7\n > Real Length: 7",
+                 "[SPHERES] \n > Amount: 2\n > Depth: 2\n > Complete Length: 3\n > Real Length: 3"):
+        assert line in log, line
+    # the gizmo walk as text (RD:92-117): every node of both heaps, labelled (position, object index)
+    mesh_dump, sphere_dump = m.OnDrawGizmos()
+    md = open(mesh_dump).read().splitlines()
+    assert len(md) == 7 and md[0].startswith("(0, -1) ")
+    leaf_ids = sorted(int(l.split(",")[1].split(")")[0]) for l in md if ", -1)" not in l)
+    assert leaf_ids == [0, 1, 2]
+    assert len(open(sphere_dump).read().splitlines()) == 3
+    m.OnDisable()
+
+
+def write_rgbe(path, rgb, rle):
+    """Minimal Radiance writer for the test (flat or new-style RLE scanlines), top row first as the format stores it."""
+    h, w, _ = rgb.shape
+    mx = rgb.max(axis=2)
+    e = np.where(mx > 1e-32, np.floor(np.log2(np.maximum(mx, 1e-38))) + 1, 0).astype(np.int32)
+    scale = np.where(mx > 1e-32, np.ldexp(1.0, 8 - e), 0.0)
+    px = np.zeros((h, w, 4), np.uint8)
+    px[..., :3] = np.clip(rgb * scale[..., None], 0, 255).astype(np.uint8)
+    px[..., 3] = np.where(mx > 1e-32, e + 128, 0).astype(np.uint8)
+    with open(path, "wb") as f:
+        f.write(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n" + f"-Y {h} +X {w}\n".encode())
+        for y in range(h):
+            if not rle:
+                f.write(px[y].tobytes())
+                continue
+            f.write(bytes([2, 2, w >> 8, w & 255]))
+            for c in range(4):
+                row = px[y, :, c]
+                i = 0
+                while i < w:                                       # literal runs of up to 128 (a valid, if uncompressed, RLE stream)
+                    n = min(128, w - i)
+                    f.write(bytes([n]) + row[i:i + n].tobytes())
+                    i += n
+
+
+@pytest.mark.parametrize("rle", [False, True])
+def test_hdr_file_as_skybox_texture(gpu_ctx, tmp_path, rle):
+    rng = np.random.default_rng(5)
+    h, w = 48, 96
+    yy, xx = np.mgrid[0:h, 0:w]
+    rgb = np.stack([0.2 + 2.5 * (xx / w), 0.1 + (yy / h) ** 2 * 6.0, 0.3 + 0.2 * np.sin(xx / 7.0) ** 2], axis=2) * rng.uniform(0.8, 1.2, (h, w, 1))
+    path = str(tmp_path / ("sky_rle.hdr" if rle else "sky_flat.hdr"))
+    write_rgbe(path, rgb.astype(np.float64), rle)
+    sky = host_io.load_hdr(path)                                   # (H, W, 4) float32, row 0 = bottom
+    assert sky.shape == (h, w, 4) and np.isfinite(sky).all() and (sky[..., 3] == 1).all()
+    err = np.abs(sky[::-1, :, :3] - rgb)                           # RGBE: 8 mantissa bits SHARED at the exponent of the largest channel
+    assert (err <= rgb.max(axis=2, keepdims=True) * 2.0 ** -7).all()
+    sc = scenes.mixed_test_scene(128, 80, sky=sky)
+    m = RayTraceMaster(gpu_ctx, sc)
+    m.OnRenderImage()
+    got = m._target.GetPixels()
+    m.OnDisable()
+    o = pyoracle.Oracle(sc)
+    nodes, tri, root, _, _ = debug_build_blas(sc.mesh_objects, sc.vertices, sc.indices)
+    o.set_blas(nodes, tri, root)
+    assert bits_equal(got, o.render(mode=1, threads=8))
+    assert (got[-1, :, :3].max(axis=1) > 0).all()                  # the top row looks at the sky: the loaded texels are in the frame
+
+
+def test_screenshot_of_gpu_frame_equals_screenshot_of_oracle_frame(gpu_ctx, tmp_path):
+    sc = scenes.mixed_test_scene(144, 88)
+    m = RayTraceMaster(gpu_ctx, sc)
+    for _ in range(4):
+        m.OnRenderImage()
+    shot = m.CaptureScreenshot(str(tmp_path / "Screenshots"), 12.5)          # RM:761-763: "<Time.time>-<_currentSample>.png"
+    assert os.path.basename(shot) == "12.5-4.png"
+    m.OnDisable()
+    o = pyoracle.Oracle(sc)
+    nodes, tri, root, _, _ = debug_build_blas(sc.mesh_objects, sc.vertices, sc.indices)
+    o.set_blas(nodes, tri, root)
+    acc = np.zeros((sc.height, sc.width, 4), np.float32)
+    for i in range(4):
+        ox, oy, sd = scenes.frame_uniforms(i)
+        o.set_frame((ox, oy), sd)
+        acc = pyoracle.accumulate(o.render(mode=1, threads=8), acc, i)
+    ref_png = str(tmp_path / "oracle.png")
+    host_io.write_png(ref_png, acc)
+    assert open(shot, "rb").read() == open(ref_png, "rb").read()
+    host_io.write_pfm(str(tmp_path / "frame.pfm"), acc)
+    assert os.path.getsize(str(tmp_path / "frame.pfm")) > sc.width * sc.height * 12

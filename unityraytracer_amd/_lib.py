@@ -24,7 +24,8 @@ ABI_SYMBOLS = [
     "urt_texture_unpack_rows", "urt_set_option", "urt_get_counters", "urt_reset_counters", "urt_debug_build_blas", "urt_debug_get_blas", "urt_debug_blas_cache_stats",
     "urt_host_compute_normals", "urt_host_mesh_leaf_bounds", "urt_host_sphere_leaf_bounds", "urt_host_object_bvh_length",
     "urt_host_build_object_bvh", "urt_host_last_error", "urt_host_load_hdr", "urt_host_write_pfm", "urt_host_write_png",
-    "urt_host_io_last_error",
+    "urt_host_io_last_error", "urt_host_log", "urt_host_log_scene_counts", "urt_host_log_tree_report", "urt_host_dump_bvh",
+    "urt_host_debug_last_error",
 ]
 
 
@@ -103,6 +104,11 @@ def load():
         "urt_host_write_pfm": ([C.c_char_p, vp, i, i], i),
         "urt_host_write_png": ([C.c_char_p, vp, i, i], i),
         "urt_host_io_last_error": ([], C.c_char_p),
+        "urt_host_log": ([C.c_char_p, i, i, C.c_char_p], i),
+        "urt_host_log_scene_counts": ([C.c_char_p, i, i, i, i, i, i], i),
+        "urt_host_log_tree_report": ([C.c_char_p, i, i, i, i, i, i, i], i),
+        "urt_host_dump_bvh": ([C.c_char_p, vp, i, i, vp, vp, pi], i),
+        "urt_host_debug_last_error": ([], C.c_char_p),
     }
     assert sorted(protos) == sorted(ABI_SYMBOLS)
     for name, (args, res) in protos.items():

@@ -63,6 +63,7 @@ class RayTraceMaster:
         self._treesNeedRebuilding = True             # RM:24
         self._rayTraceObjects = []                   # RM:22 (empty: the scene arrives pre-flattened in `scene`)
         self.SkyboxTexture = None                    # RM:10
+        self.rayDebug = None                         # RM:9: a RayTraceDebug (ray_trace_debug.py) or None
         self._meshObjectBuffer = self._vertexBuffer = self._indexBuffer = self._normalBuffer = None
         self._sphereBuffer = self._meshObjectBVHBuffer = self._sphereBVHBuffer = None
         self.screen_width, self.screen_height = scene.width, scene.height
@@ -108,6 +109,8 @@ class RayTraceMaster:
             if len(s.mesh_objects) else np.zeros(0, scenes.BVHNODE_DT)
         s.sphere_bvh = host_scene.build_object_bvh(host_scene.sphere_leaf_bounds(s.spheres, literal_leaf_bounds)) \
             if len(s.spheres) else np.zeros(0, scenes.BVHNODE_DT)
+        if self.rayDebug is not None:                                             # RM:331-335
+            self.rayDebug.LogSceneCounts(len(s.spheres), len(s.mesh_objects), len(s.vertices), len(s.indices), len(s.normals))
 
     # RM:233-252
     def CreateComputeBuffer(self, buffer, data: np.ndarray, stride: int):
@@ -127,8 +130,16 @@ class RayTraceMaster:
             self.RayTraceShader.SetBuffer(0, name, buffer)
 
     # RM:725-746 (upload half)
+    @staticmethod
+    def tree_depth(n_objects: int) -> int:
+        """MeshDepth / SphereDepth of CreateBVH (RM:683,705): ceil(log2 n) + 1 levels; 0 for an empty list."""
+        return 0 if n_objects <= 0 else int(math.ceil(math.log2(n_objects))) + 1 if n_objects > 1 else 1
+
     def RebuildTrees(self):
         s = self.scene
+        if self.rayDebug is not None:                                             # RM:731-735
+            self.rayDebug.LogTreeReport(len(s.mesh_objects), self.tree_depth(len(s.mesh_objects)), len(s.mesh_bvh),
+                                        len(s.spheres), self.tree_depth(len(s.spheres)), len(s.sphere_bvh))
         self._meshObjectBuffer = self.CreateComputeBuffer(self._meshObjectBuffer, s.mesh_objects, self.MeshObjectStructSize)
         self._vertexBuffer = self.CreateComputeBuffer(self._vertexBuffer, np.ascontiguousarray(s.vertices, np.float32), 12)
         self._indexBuffer = self.CreateComputeBuffer(self._indexBuffer, np.ascontiguousarray(s.indices, np.int32), 4)
@@ -214,6 +225,16 @@ class RayTraceMaster:
         path = os.path.join(directory, f"{time_seconds:g}-{self._currentSample}.png")
         host_io.write_png(path, self._converged.GetPixels())
         return path
+
+    # RM:869-878: the editor gizmos become text dumps of the two object-level heaps (RayTraceDebug.DrawBVHTree)
+    def OnDrawGizmos(self):
+        if self.rayDebug is not None:
+            s = self.scene
+            self.rayDebug.DrawBVHTree(s.mesh_bvh, self.tree_depth(len(s.mesh_objects)), 0)
+            mesh_dump = getattr(self.rayDebug, "last_dump", None)
+            self.rayDebug.DrawBVHTree(s.sphere_bvh, self.tree_depth(len(s.spheres)), 1)
+            return mesh_dump, getattr(self.rayDebug, "last_dump", None)
+        return None, None
 
     # RM:188-212
     def OnDisable(self):
