@@ -174,6 +174,49 @@ URT_API int urt_set_option(urt_context* ctx, const char* name, int value);
 URT_API int urt_get_counters(urt_context* ctx, urt_counters* out);   /* synchronises */
 URT_API int urt_reset_counters(urt_context* ctx);
 
+/* ---- device groups: one host thread, N GPUs (SURVEY.md 8b "device list for 1/2/4/8 GPUs", 8e) ------------------------------
+ * The reference issues everything from Unity's main thread to one GPU (RM:806-810).  A host that wants the frame
+ * tile-partitioned over the GPUs of a node keeps its call sequence and swaps urt_* for urt_group_*:
+ *  - scene buffers, uniforms, textures, options and Graphics.Blit calls are REPLICATED on every rank's context (one handle
+ *    value names the same object on every rank);
+ *  - urt_group_shader_dispatch gives rank r the 8-row strips r, r+N, ... with global pixel ids (= urt_shader_dispatch_rows):
+ *    the union over the ranks is bit-identical to one full dispatch;
+ *  - accumulation stays local to the ranks' strips; urt_group_gather is the ONE exchange per frame: strips of `src_texture`
+ *    from every rank -> the full image `dst_texture` on rank 0 (pack kernels + hipMemcpyPeerAsync over xGMI, point-to-point
+ *    to the root, ordered by events, no host synchronisation; queued behind the ranks' batched frames and submitted in
+ *    bursts of up to 16);
+ *  - readback, synchronize and counters act on the whole group (pixels come from rank 0).
+ * The device list may repeat an ordinal (several ranks on one card).  urt_group_context exposes a rank's context for
+ * per-rank inspection; objects must be created through the group. */
+typedef struct urt_group urt_group;
+URT_API int urt_group_create(const int* devices, int n_devices, urt_group** out_group);
+URT_API int urt_group_destroy(urt_group* group);
+URT_API int urt_group_size(urt_group* group);
+URT_API urt_context* urt_group_context(urt_group* group, int rank);
+URT_API const char* urt_group_last_error(urt_group* group);          /* group may be NULL for create failures */
+URT_API int urt_group_buffer_create(urt_group* group, int count, int stride, urt_handle* out_buffer);            /* RM:247 */
+URT_API int urt_group_buffer_set_data(urt_group* group, urt_handle buffer, const void* data, int count);          /* RM:250 */
+URT_API int urt_group_buffer_release(urt_group* group, urt_handle buffer);
+URT_API int urt_group_texture_create(urt_group* group, int width, int height, urt_handle* out_texture);          /* RM:834-840 */
+URT_API int urt_group_texture_set_pixels(urt_group* group, urt_handle texture, const float* rgba);
+URT_API int urt_group_texture_get_pixels(urt_group* group, urt_handle texture, float* rgba);                     /* rank 0's image */
+URT_API int urt_group_texture_release(urt_group* group, urt_handle texture);
+URT_API int urt_group_shader_set_buffer(urt_group* group, int kernel, const char* name, urt_handle buffer);      /* RM:787-794 */
+URT_API int urt_group_shader_set_texture(urt_group* group, int kernel, const char* name, urt_handle texture);    /* RM:776, 803 */
+URT_API int urt_group_shader_set_matrix(urt_group* group, const char* name, const float* m16);                   /* RM:773-774 */
+URT_API int urt_group_shader_set_vector(urt_group* group, const char* name, const float* v4);                    /* RM:777 */
+URT_API int urt_group_shader_set_float(urt_group* group, const char* name, float value);                         /* RM:778 */
+URT_API int urt_group_shader_set_int(urt_group* group, const char* name, int value);                             /* RM:780-784 */
+URT_API int urt_group_set_option(urt_group* group, const char* name, int value);
+URT_API int urt_group_shader_dispatch(urt_group* group, int kernel, int groups_x, int groups_y, int groups_z);   /* RM:806-810, partitioned */
+URT_API int urt_group_blit_add(urt_group* group, urt_handle src, urt_handle dst, float sample);                  /* RM:817-818 */
+URT_API int urt_group_blit(urt_group* group, urt_handle src, urt_handle dst);                                    /* RM:819 */
+URT_API int urt_group_gather(urt_group* group, urt_handle src_texture, urt_handle dst_texture);
+URT_API int urt_group_flush(urt_group* group);
+URT_API int urt_group_synchronize(urt_group* group);
+URT_API int urt_group_get_counters(urt_group* group, urt_counters* out);   /* summed over the ranks; dispatches/launches/trace_ms = the largest rank's */
+URT_API int urt_group_reset_counters(urt_group* group);
+
 /* ---- host-side scene preparation (no GPU needed) ---------------------- */
 /* RayTraceMaster.ComputeNormals (RM:340-368): per-vertex sum of the un-normalised face normals of every index slot whose
  * vertex POSITION equals this vertex's (weld across all meshes), in ascending slot order, then Vector3.Normalize —

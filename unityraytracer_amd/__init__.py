@@ -10,5 +10,5 @@ from . import host_io, host_scene, scenes, strips  # noqa: F401
 from ._lib import ABI_SYMBOLS, LIB_PATH, UrtError  # noqa: F401
 from .ray_trace_debug import RayTraceDebug  # noqa: F401
 from .ray_trace_master import RayTraceMaster, RayTraceObject  # noqa: F401
-from .unity_api import (ComputeBuffer, ComputeShader, Context, Graphics, Material, RenderTexture, Texture2D,  # noqa: F401
+from .unity_api import (ComputeBuffer, ComputeShader, Context, DeviceGroup, Graphics, Material, RenderTexture, Texture2D,  # noqa: F401
                         debug_build_blas)

@@ -26,6 +26,12 @@ ABI_SYMBOLS = [
     "urt_host_build_object_bvh", "urt_host_last_error", "urt_host_load_hdr", "urt_host_write_pfm", "urt_host_write_png",
     "urt_host_io_last_error", "urt_host_log", "urt_host_log_scene_counts", "urt_host_log_tree_report", "urt_host_dump_bvh",
     "urt_host_debug_last_error",
+    "urt_group_create", "urt_group_destroy", "urt_group_size", "urt_group_context", "urt_group_last_error", "urt_group_buffer_create",
+    "urt_group_buffer_set_data", "urt_group_buffer_release", "urt_group_texture_create", "urt_group_texture_set_pixels",
+    "urt_group_texture_get_pixels", "urt_group_texture_release", "urt_group_shader_set_buffer", "urt_group_shader_set_texture",
+    "urt_group_shader_set_matrix", "urt_group_shader_set_vector", "urt_group_shader_set_float", "urt_group_shader_set_int",
+    "urt_group_set_option", "urt_group_shader_dispatch", "urt_group_blit_add", "urt_group_blit", "urt_group_gather", "urt_group_flush",
+    "urt_group_synchronize", "urt_group_get_counters", "urt_group_reset_counters",
 ]
 
 
@@ -109,6 +115,33 @@ def load():
         "urt_host_log_tree_report": ([C.c_char_p, i, i, i, i, i, i, i], i),
         "urt_host_dump_bvh": ([C.c_char_p, vp, i, i, vp, vp, pi], i),
         "urt_host_debug_last_error": ([], C.c_char_p),
+        "urt_group_create": ([pi, i, C.POINTER(vp)], i),
+        "urt_group_destroy": ([vp], i),
+        "urt_group_size": ([vp], i),
+        "urt_group_context": ([vp, i], vp),
+        "urt_group_last_error": ([vp], C.c_char_p),
+        "urt_group_buffer_create": ([vp, i, i, C.POINTER(u64)], i),
+        "urt_group_buffer_set_data": ([vp, u64, vp, i], i),
+        "urt_group_buffer_release": ([vp, u64], i),
+        "urt_group_texture_create": ([vp, i, i, C.POINTER(u64)], i),
+        "urt_group_texture_set_pixels": ([vp, u64, vp], i),
+        "urt_group_texture_get_pixels": ([vp, u64, vp], i),
+        "urt_group_texture_release": ([vp, u64], i),
+        "urt_group_shader_set_buffer": ([vp, i, C.c_char_p, u64], i),
+        "urt_group_shader_set_texture": ([vp, i, C.c_char_p, u64], i),
+        "urt_group_shader_set_matrix": ([vp, C.c_char_p, vp], i),
+        "urt_group_shader_set_vector": ([vp, C.c_char_p, vp], i),
+        "urt_group_shader_set_float": ([vp, C.c_char_p, f], i),
+        "urt_group_shader_set_int": ([vp, C.c_char_p, i], i),
+        "urt_group_set_option": ([vp, C.c_char_p, i], i),
+        "urt_group_shader_dispatch": ([vp, i, i, i, i], i),
+        "urt_group_blit_add": ([vp, u64, u64, f], i),
+        "urt_group_blit": ([vp, u64, u64], i),
+        "urt_group_gather": ([vp, u64, u64], i),
+        "urt_group_flush": ([vp], i),
+        "urt_group_synchronize": ([vp], i),
+        "urt_group_get_counters": ([vp, C.POINTER(Counters)], i),
+        "urt_group_reset_counters": ([vp], i),
     }
     assert sorted(protos) == sorted(ABI_SYMBOLS)
     for name, (args, res) in protos.items():

@@ -1177,3 +1177,10 @@ int urt_debug_get_blas(float* nodes, int32_t* tri_index, int32_t* mesh_root, int
 }
 
 }  // extern "C"
+
+// ---- internal accessors for group.cpp (not part of the C ABI) ----------------------------------------------------------
+namespace urtd {
+hipStream_t context_stream(urt_context* ctx) { return ctx->stream; }
+int context_device(urt_context* ctx) { return ctx->device; }
+int context_pending_frames(urt_context* ctx) { return ctx->pend.n; }
+}  // namespace urtd

@@ -75,6 +75,75 @@ class Context:
         self.check(self.lib.urt_reset_counters(self._h))
 
 
+class _GroupLib:
+    """Maps the per-context entry points onto their urt_group_* counterparts, so that ComputeBuffer / RenderTexture /
+    ComputeShader / Graphics / RayTraceMaster drive a DeviceGroup exactly as they drive a Context."""
+
+    def __init__(self, lib):
+        self._lib = lib
+
+    def __getattr__(self, name):
+        if not name.startswith("urt_"):
+            raise AttributeError(name)
+        return getattr(self._lib, "urt_group_" + name[4:])       # AttributeError for calls a group does not offer
+
+
+class DeviceGroup:
+    """urt_group: ONE host thread drives N GPUs (include/urt.h "device groups").  Scene, uniforms, textures and blits are
+    replicated on every rank, Dispatch is partitioned into 8-row strips with global pixel ids, `gather` is the one exchange
+    per frame (strips -> full image on rank 0).  `devices` may repeat an ordinal (several ranks on one card)."""
+
+    def __init__(self, devices):
+        self._raw = _lib.load()
+        self.lib = _GroupLib(self._raw)
+        self._h = C.c_void_p()
+        arr = (C.c_int * len(devices))(*[int(d) for d in devices])
+        rc = self._raw.urt_group_create(arr, len(devices), C.byref(self._h))
+        if rc != 0:
+            raise UrtError(rc, self._raw.urt_group_last_error(None).decode())
+        self.devices = list(devices)
+
+    @property
+    def size(self) -> int:
+        return self._raw.urt_group_size(self._h)
+
+    def check(self, rc: int):
+        if rc != 0:
+            raise UrtError(rc, self._raw.urt_group_last_error(self._h).decode())
+
+    def close(self):
+        if self._h:
+            self._raw.urt_group_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def synchronize(self):
+        self.check(self._raw.urt_group_synchronize(self._h))
+
+    def flush(self):
+        self.check(self._raw.urt_group_flush(self._h))
+
+    def set_option(self, name: str, value: int):
+        self.check(self._raw.urt_group_set_option(self._h, name.encode(), int(value)))
+
+    def gather(self, src: "RenderTexture", dst: "RenderTexture"):
+        """The ONE exchange per frame: every rank's strips of `src` -> the full image `dst` on rank 0."""
+        self.check(self._raw.urt_group_gather(self._h, src.handle, dst.handle))
+
+    def counters(self) -> dict:
+        c = Counters()
+        self.check(self._raw.urt_group_get_counters(self._h, C.byref(c)))
+        return c.as_dict()
+
+    def reset_counters(self):
+        self.check(self._raw.urt_group_reset_counters(self._h))
+
+
 class ComputeBuffer:
     """UnityEngine.ComputeBuffer (RM:247-250)."""
 
