@@ -126,23 +126,30 @@ def main():
     ctx.set_option("time_dispatch", 1)
     master = RayTraceMaster(ctx, scene, rank=rank, world_size=world)
 
-    # ---- multi-GPU frame-end gather, software-pipelined ---------------------------------------------------------------
-    # Frame i's strips are packed on the render stream; the ONE collective of the frame (gather to rank 0) runs on a second
-    # stream and overlaps with the rendering of frame i+1; rank 0 de-interleaves frame i on that second stream as well.
-    # Buffers are double-buffered and every reuse is ordered by events.  URT_BENCH_NO_OVERLAP=1 serialises everything.
+    # ---- multi-GPU frame-end gather, pipelined in bursts --------------------------------------------------------------
+    # Every frame ends with ONE collective (gather of the rank's accumulated strips to rank 0).  The library batches B
+    # consecutive frames into one persistent launch per rank (frames_per_launch, explicit because the stream is shared with
+    # torch); frame i's strips are packed into their own buffer by a pack kernel queued behind the batch.  After B frames
+    # the batch is submitted and its B gathers run on a second stream — overlapping with the NEXT batch's rendering — where
+    # rank 0 also de-interleaves them (urt_texture_unpack_rows_on), so that its render stream carries exactly what the other
+    # ranks' do.  Pack buffers form a ring of 2B, every reuse is ordered by events.  URT_BENCH_NO_OVERLAP=1 serialises.
     overlap = world > 1 and os.environ.get("URT_BENCH_NO_OVERLAP") != "1"
+    burst = 1
     if world > 1:
+        burst = max(1, min(16, args.frames_per_launch if args.frames_per_launch else int(os.environ.get("URT_BENCH_BURST", "8"))))
+        ctx.set_option("frames_per_launch", burst)
         n_floats = strips.packed_rows(height, world) * width * 4
-        packed = [torch.zeros(n_floats, dtype=torch.float32, device=device) for _ in range(2)]
-        gathered = [[torch.empty(n_floats, dtype=torch.float32, device=device) for _ in range(world)] for _ in range(2)] if rank == 0 else [None, None]
+        ring = 2 * burst
+        packed = [torch.zeros(n_floats, dtype=torch.float32, device=device) for _ in range(ring)]
+        gathered = [[torch.empty(n_floats, dtype=torch.float32, device=device) for _ in range(world)] for _ in range(ring)] if rank == 0 else [None] * ring
         comm_stream = torch.cuda.Stream(device=device) if overlap else main_stream
-        ev_pack = [torch.cuda.Event() for _ in range(2)]
-        ev_gather = [torch.cuda.Event() for _ in range(2)]
+        ev_batch = torch.cuda.Event()
+        ev_gather = [torch.cuda.Event() for _ in range(ring)]
         full = None
         if rank == 0:
             from unityraytracer_amd import RenderTexture
             full = RenderTexture(ctx, width, height)
-    state = {"i": 0, "pending": None}
+    state = {"i": 0, "pending": []}
 
     def do_gather(slot):
         if backend == "nccl":
@@ -155,40 +162,44 @@ def main():
                 for r in range(world):
                     gathered[slot][r].copy_(parts[r])
 
-    def unpack(slot):
-        if rank == 0:
-            for r in range(world):
-                full.unpack_rows(r, world, gathered[slot][r].data_ptr())
+    def submit():
+        """Submit the deferred batch (trace launch + blends + packs) and run its gathers on the communication stream."""
+        if not state["pending"]:
+            return
+        ctx.flush()
+        ev_batch.record(main_stream)
+        with torch.cuda.stream(comm_stream):
+            comm_stream.wait_event(ev_batch)
+            for slot in state["pending"]:
+                do_gather(slot)
+                if rank == 0:
+                    for r in range(world):
+                        full.unpack_rows(r, world, gathered[slot][r].data_ptr(), stream=comm_stream.cuda_stream)
+                ev_gather[slot].record(comm_stream)
+        if not overlap:
+            main_stream.wait_event(ev_gather[state["pending"][-1]])
+        state["pending"] = []
 
     def step():
-        master.OnRenderImage()
         if world == 1:
+            master.OnRenderImage()
             return
         i = state["i"]
-        slot = i % 2
-        if i >= 2:
-            main_stream.wait_event(ev_gather[slot])                       # frame i-2's gather (and de-interleave) are done with this slot
-        master._converged.pack_rows(rank, world, packed[slot].data_ptr())
-        ev_pack[slot].record(main_stream)
-        with torch.cuda.stream(comm_stream):
-            comm_stream.wait_event(ev_pack[slot])
-            do_gather(slot)
-            if rank == 0:
-                # de-interleave on the communication stream too: rank 0's render stream carries the same work as every
-                # other rank's (trace + accumulate + pack) and frame i+1 renders while frame i is gathered and unpacked
-                ctx.set_stream(comm_stream.cuda_stream)
-                unpack(slot)
-                ctx.set_stream(main_stream.cuda_stream)
-            ev_gather[slot].record(comm_stream)
-        if not overlap:
-            main_stream.wait_event(ev_gather[slot])
-        state["pending"] = slot
+        slot = i % ring
+        if i >= ring:
+            main_stream.wait_event(ev_gather[slot])                       # the gather that last used this pack buffer is done with it
+        master.OnRenderImage()                                            # deferred: dispatch of this rank's strips + accumulate
+        master._converged.pack_rows(rank, world, packed[slot].data_ptr()) # deferred behind them
+        state["pending"].append(slot)
         state["i"] = i + 1
+        if len(state["pending"]) >= burst:
+            submit()
 
     def drain():
-        if world > 1 and state["pending"] is not None:
-            main_stream.wait_event(ev_gather[0]); main_stream.wait_event(ev_gather[1])
-            state["pending"] = None
+        if world > 1:
+            submit()
+            for e in ev_gather:
+                main_stream.wait_event(e)
 
     def fence():
         ctx.synchronize()                     # submits the library's deferred frames and waits for its stream
@@ -316,7 +327,7 @@ def main():
             "config": {"workload": f"{args.config}: {scene.name}, {scene.n_triangles} triangles + triangle BVH, {len(scene.spheres)} spheres, "
                                    f"ground plane, equirect sky; numBounces {scene.num_bounces}, numRays {scene.num_rays}",
                        "frame": [width, height], "pixels_per_gpu": width * height // world,
-                       "partition": ("8-row strips round-robin over ranks, one gather per frame" + (", gather overlapped with the next frame" if overlap else "")) if world > 1 else "single GPU",
+                       "partition": (f"8-row strips round-robin over ranks, one gather per frame; {burst} frames per launch, each burst's gathers" + (" overlap the next burst's rendering" if overlap else " serialised")) if world > 1 else "single GPU",
                        "rays_per_step": int(total_rays / args.steps), "kernel_mode": args.kernel_mode if args.kernel_mode is not None else 3},
             "roofline": roofline, "cpu_baseline": cpu,
         }

@@ -133,6 +133,11 @@ URT_API int urt_texture_pack_rows(urt_context* ctx, urt_handle texture, int firs
                                   void* device_dst, uint64_t* out_bytes);
 URT_API int urt_texture_unpack_rows(urt_context* ctx, urt_handle texture, int first_group_row, int row_stride,
                                     const void* device_src);
+/* The same de-interleave issued on a CALLER-GIVEN stream (e.g. the communication stream the gather ran on), without touching
+ * the context's own stream: the caller orders it (the image must not be in use by the context's queued work — a dedicated
+ * gather target never is).  Lets rank 0 de-interleave frame i while its render stream is already on frame i+1. */
+URT_API int urt_texture_unpack_rows_on(urt_context* ctx, urt_handle texture, int first_group_row, int row_stride,
+                                       const void* device_src, void* hip_stream);
 
 /* ---- measurement -------------------------------------------------------------------------- */
 typedef struct urt_counters {

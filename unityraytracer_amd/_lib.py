@@ -21,7 +21,7 @@ ABI_SYMBOLS = [
     "urt_texture_create_external", "urt_texture_set_pixels", "urt_texture_get_pixels", "urt_texture_get_info", "urt_texture_release",
     "urt_shader_set_buffer", "urt_shader_set_texture", "urt_shader_set_matrix", "urt_shader_set_vector", "urt_shader_set_float",
     "urt_shader_set_int", "urt_shader_dispatch", "urt_shader_dispatch_rows", "urt_blit_add", "urt_blit", "urt_texture_pack_rows",
-    "urt_texture_unpack_rows", "urt_set_option", "urt_get_counters", "urt_reset_counters", "urt_debug_build_blas", "urt_debug_get_blas", "urt_debug_blas_cache_stats",
+    "urt_texture_unpack_rows", "urt_texture_unpack_rows_on", "urt_set_option", "urt_get_counters", "urt_reset_counters", "urt_debug_build_blas", "urt_debug_get_blas", "urt_debug_blas_cache_stats",
     "urt_host_compute_normals", "urt_host_mesh_leaf_bounds", "urt_host_sphere_leaf_bounds", "urt_host_object_bvh_length",
     "urt_host_build_object_bvh", "urt_host_last_error", "urt_host_load_hdr", "urt_host_write_pfm", "urt_host_write_png",
     "urt_host_io_last_error", "urt_host_log", "urt_host_log_scene_counts", "urt_host_log_tree_report", "urt_host_dump_bvh",
@@ -94,6 +94,7 @@ def load():
         "urt_blit": ([vp, u64, u64], i),
         "urt_texture_pack_rows": ([vp, u64, i, i, vp, C.POINTER(u64)], i),
         "urt_texture_unpack_rows": ([vp, u64, i, i, vp], i),
+        "urt_texture_unpack_rows_on": ([vp, u64, i, i, vp, vp], i),
         "urt_set_option": ([vp, C.c_char_p, i], i),
         "urt_get_counters": ([vp, C.POINTER(Counters)], i),
         "urt_reset_counters": ([vp], i),

@@ -1009,6 +1009,24 @@ int urt_texture_pack_rows(urt_context* ctx, urt_handle texture, int first_group_
   return pack_impl(ctx, texture, first_group_row, row_stride, device_dst, true, out_bytes);
 }
 
+int urt_texture_unpack_rows_on(urt_context* ctx, urt_handle texture, int first_group_row, int row_stride, const void* device_src,
+                               void* hip_stream) {
+  if (!ctx) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  if (!device_src || !hip_stream) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "device_src / hip_stream is NULL");
+  Texture* t = find_texture(ctx, texture);
+  if (!t) return fail(ctx, URT_ERR_INVALID_HANDLE, "unknown texture handle");
+  if (first_group_row < 0 || row_stride < 1) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "bad strip arguments");
+  if (ctx->pend.n > 0 && ctx->pend.tex == texture) { int rc = flush_pending(ctx); if (rc) return rc; }   // never the case for a gather target
+  if (in_slab(ctx, *t)) { int rc = detach_from_slab(ctx, *t); if (rc) return rc; }
+  int group_rows = (t->h + 7) / 8;
+  int n_strips = first_group_row < group_rows ? (group_rows - first_group_row + row_stride - 1) / row_stride : 0;
+  t->other_writes = true;
+  URT_HIP(ctx, hipSetDevice(ctx->device));
+  URT_HIP(ctx, launch_pack_rows(t->dev, (float4*)const_cast<void*>(device_src), t->w, t->h, first_group_row, row_stride, n_strips, false,
+                                (hipStream_t)hip_stream));
+  return URT_OK;
+}
+
 int urt_texture_unpack_rows(urt_context* ctx, urt_handle texture, int first_group_row, int row_stride, const void* device_src) {
   if (ctx && !device_src) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "device_src is NULL");
   return pack_impl(ctx, texture, first_group_row, row_stride, const_cast<void*>(device_src), false, nullptr);

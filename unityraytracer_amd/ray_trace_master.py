@@ -249,23 +249,36 @@ class RayTraceMaster:
 
     # ---- multi-GPU frame-end gather (no counterpart in the reference: it is single-GPU) -----------
     def gather_converged(self, dist, device):
-        """One collective at frame end: every rank packs its strips of `_converged` into a dense device
-        buffer (k_pack_rows), rank 0 gathers (RCCL) and de-interleaves (k_pack_rows, reverse).
-        Returns the full image on rank 0 (numpy), else None."""
+        """One collective at frame end: every rank packs its strips of `_converged` into a dense device buffer
+        (k_pack_rows), rank 0 gathers (RCCL; with the gloo backend the buffers are staged through host memory) and
+        de-interleaves (k_pack_rows, reverse).  Returns the full image on rank 0 (numpy), else None.
+        Synchronous by design (a convenience for tests and tools; bench.py pipelines the same steps on streams)."""
         import torch
         from . import strips
+        from ._lib import UrtError
+        if self._converged is None or not self._converged.handle:
+            raise UrtError(2, "gather_converged: no accumulated image yet (render a frame first)")
         n_floats = strips.packed_rows(self.screen_height, self.world_size) * self.screen_width * 4
         mine = torch.zeros(n_floats, dtype=torch.float32, device=device)
+        if mine.is_cuda:
+            # the zero fill runs on torch's current stream, the pack kernel on the library's own stream: order them
+            torch.cuda.current_stream(device).synchronize()
         self._converged.pack_rows(self.rank, self.world_size, mine.data_ptr())
         self.ctx.synchronize()
-        parts = strips.gather_to_root(dist, mine, self.rank, self.world_size)
+        staged = dist.get_backend() == "gloo"
+        parts = strips.gather_to_root(dist, mine.cpu() if staged else mine, self.rank, self.world_size)
         if mine.is_cuda:
             torch.cuda.synchronize(device)
         if self.rank != 0:
             return None
         full = RenderTexture(self.ctx, self.screen_width, self.screen_height)
+        keep = []
         for r, p in enumerate(parts):
-            full.unpack_rows(r, self.world_size, p.data_ptr())
-        out = full.GetPixels()
+            pd = p.to(device) if staged else p
+            keep.append(pd)
+            if pd.is_cuda:
+                torch.cuda.current_stream(device).synchronize()             # the upload (torch's stream) before the unpack (library's stream)
+            full.unpack_rows(r, self.world_size, pd.data_ptr())
+        out = full.GetPixels()                                             # synchronises
         full.Release()
         return out

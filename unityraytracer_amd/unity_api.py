@@ -209,8 +209,13 @@ class RenderTexture:
     def pack_rows(self, first_group_row: int, row_stride: int, device_dst: int):
         self.ctx.check(self.ctx.lib.urt_texture_pack_rows(self.ctx._h, self.handle, first_group_row, row_stride, C.c_void_p(device_dst), None))
 
-    def unpack_rows(self, first_group_row: int, row_stride: int, device_src: int):
-        self.ctx.check(self.ctx.lib.urt_texture_unpack_rows(self.ctx._h, self.handle, first_group_row, row_stride, C.c_void_p(device_src)))
+    def unpack_rows(self, first_group_row: int, row_stride: int, device_src: int, stream: int | None = None):
+        """De-interleave packed strips into this image; `stream` = a caller-ordered hipStream_t (include/urt.h
+        urt_texture_unpack_rows_on), default = the context's stream."""
+        if stream:
+            self.ctx.check(self.ctx.lib.urt_texture_unpack_rows_on(self.ctx._h, self.handle, first_group_row, row_stride, C.c_void_p(device_src), C.c_void_p(stream)))
+        else:
+            self.ctx.check(self.ctx.lib.urt_texture_unpack_rows(self.ctx._h, self.handle, first_group_row, row_stride, C.c_void_p(device_src)))
 
 
 Texture2D = RenderTexture   # the sky is an ordinary RGBA32F image here
