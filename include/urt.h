@@ -156,7 +156,10 @@ typedef struct urt_counters {
   uint32_t watchdog_trips; /* waves that hit a persistent kernel's iteration cap: always 0 unless there is a bug */
   uint64_t launches;      /* trace-kernel launches those dispatches became (< dispatches when frames were batched) */
 } urt_counters;
-/* Options: "frames_per_launch" (0 = auto: own stream -> up to 16 frames / ~32 M pixels per launch, caller's stream -> 1;
+/* Options: "blas_builder" (0 = binned-SAH triangle BVH built on host threads, the default: best trees; 1 = LBVH built on the GPU
+ *                          from the uploaded buffers — Morton sort + Karras hierarchy, csrc/lbvh.hip: milliseconds instead of tens
+ *                          of milliseconds for scenes whose objects move; same pixels),
+ *          "frames_per_launch" (0 = auto: own stream -> up to 16 frames / ~32 M pixels per launch, caller's stream -> 1;
  *                               1 = every dispatch is its own launch; 2..16 = batch that many, also on a caller's stream),
  *          "count_stats" (0/1: per-dispatch traversal counters, slower build of the kernel),
  *          "time_dispatch" (0/1: bracket each dispatch with HIP events, read by urt_get_counters),
@@ -281,6 +284,12 @@ URT_API int urt_debug_build_blas(const void* mesh_objects, int n_meshes, const f
  * index-slot numbers (i of RS:243) in leaf order; mesh_root / mesh_first_tri = one entry per MeshObject.
  * Any pointer may be NULL. */
 URT_API int urt_debug_get_blas(float* nodes, int32_t* tri_index, int32_t* mesh_root, int32_t* mesh_first_tri);
+/* The triangle BVH of the context's CURRENT device scene, whichever builder made it ("blas_builder" option): prepares the
+ * scene if it is stale (as the next dispatch would).  scene_info reports sizes, the depth of the deepest leaf and the host
+ * wall time the last preparation took; read_scene_blas copies the nodes (n_nodes x 16 floats), the index slot of every
+ * leaf-order triangle and the MeshObject roots back from the GPU.  Any pointer may be NULL. */
+URT_API int urt_debug_scene_info(urt_context* ctx, int* out_n_nodes, int* out_n_tris, int* out_max_depth, float* out_prepare_ms);
+URT_API int urt_debug_read_scene_blas(urt_context* ctx, float* nodes, int32_t* tri_index, int32_t* mesh_root);
 /* Scene preparation of a context keeps the triangle BVH of every MeshObject and reuses it at the next preparation when the
  * MeshObject's matrix and the positions behind its index slots are unchanged (the reference re-uploads every buffer when
  * any object moves, RM:262-336).  Reports how many MeshObject BVHs were reused / built since the context was created. */

@@ -5,7 +5,7 @@ cd "$(dirname "$0")/../unityraytracer_amd" || exit 1
 OUT=${1:-/tmp/urt_remarks.so}; shift
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -fvisibility=hidden -pthread -Xarch_host -march=x86-64-v3 \
   -Wall -Wno-unused-function -Rpass-analysis=kernel-resource-usage "$@" -o "$OUT" \
-  csrc/kernels.hip csrc/context.cpp csrc/blas_builder.cpp csrc/host_scene.cpp csrc/host_io.cpp csrc/host_debug.cpp csrc/group.cpp 2> /tmp/urt_remarks.log
+  csrc/kernels.hip csrc/lbvh.hip csrc/context.cpp csrc/blas_builder.cpp csrc/host_scene.cpp csrc/host_io.cpp csrc/host_debug.cpp csrc/group.cpp 2> /tmp/urt_remarks.log
 rc=$?
 grep -E "error" -A6 /tmp/urt_remarks.log | head -40
 python3 - <<'PY'

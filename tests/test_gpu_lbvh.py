@@ -1,0 +1,149 @@
+"""GPU: the triangle BVH built ON the GPU (csrc/lbvh.hip, urt_set_option("blas_builder", 1): Morton sort + Karras hierarchy +
+bottom-up fit) is structurally valid, keeps the top-of-forest numbering the trace kernel relies on, gives bit-identical frames
+to the host-built SAH tree and to the oracle, reports bad scene data like the host builder, and prepares the 983,040-triangle
+C5 scene in milliseconds (SURVEY.md §8f row f2 "GPU BLAS build (LBVH) for dynamic scenes")."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle
+from test_blas import validate
+from unityraytracer_amd import RayTraceMaster, UrtError, debug_build_blas, scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def bits_equal(a, b):
+    return np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@pytest.fixture()
+def lbvh(gpu_ctx):
+    gpu_ctx.set_option("kernel_mode", 3)
+    gpu_ctx.set_option("blas_builder", 1)
+    yield gpu_ctx
+    gpu_ctx.set_option("blas_builder", 0)
+
+
+def render(ctx, sc, frames=1):
+    m = RayTraceMaster(ctx, sc)
+    for _ in range(frames):
+        m.OnRenderImage()
+    return m, m._target.GetPixels(), m._converged.GetPixels()
+
+
+@pytest.mark.parametrize("scene_fn", [lambda: scenes.mixed_test_scene(96, 64, blob=(40, 31)), lambda: scenes.many_meshes_scene(n=70, level=1),
+                                      lambda: scenes.config3(128, 72, slices=60, stacks=41, sky=scenes.make_sky(64, 32))])
+def test_gpu_built_tree_is_valid_and_top_is_breadth_first(lbvh, scene_fn):
+    sc = scene_fn()
+    m, _, _ = render(lbvh, sc)
+    nodes, tri, root, info = lbvh.read_scene_blas(len(sc.mesh_objects))
+    m.OnDisable()
+    assert len(tri) == sc.n_triangles and sorted(tri.tolist()) == list(range(0, 3 * sc.n_triangles, 3))     # every index slot exactly once
+    assert validate(sc, nodes, tri, root) <= info["max_depth"]                # boxes nest, triangles inside their leaf boxes, depth bound holds
+    # interior roots are nodes 0..k-1 in MeshObject order and a breadth-first walk meets 0, 1, 2, ... (LDS top of the forest)
+    roots = [int(r) for r in root if 0 <= r != 0x7FFFFFFF]
+    assert roots == list(range(len(roots)))
+    queue, order = list(roots), []
+    while queue and len(order) < 256:
+        n = queue.pop(0)
+        order.append(n)
+        queue += [int(c) for c in nodes[n][12:14].view(np.int32) if c >= 0]
+    assert order == list(range(len(order)))
+    seen = set()
+    for n in nodes:
+        for c in n[12:14].view(np.int32):
+            if c >= 0:
+                assert int(c) not in seen and int(c) < len(nodes)
+                seen.add(int(c))
+    assert len(seen) == len(nodes) - len(roots)                               # every non-root node has exactly one parent
+
+
+@pytest.mark.parametrize("scene_fn", [lambda: scenes.mixed_test_scene(160, 96), lambda: scenes.many_meshes_scene(128, 80, n=120, level=0)])
+def test_frames_equal_host_built_tree_and_oracle(gpu_ctx, scene_fn):
+    sc = scene_fn()
+    gpu_ctx.set_option("kernel_mode", 3)
+    gpu_ctx.set_option("blas_builder", 0)
+    m, t0, c0 = render(gpu_ctx, sc, frames=3)
+    m.OnDisable()
+    gpu_ctx.set_option("blas_builder", 1)
+    try:
+        m, t1, c1 = render(gpu_ctx, sc, frames=3)
+        m.OnDisable()
+        # the other kernel modes walk the same device tree
+        for mode in (0, 2):
+            gpu_ctx.set_option("kernel_mode", mode)
+            m, t2, _ = render(gpu_ctx, sc, frames=3)
+            m.OnDisable()
+            assert bits_equal(t2, t0), mode
+    finally:
+        gpu_ctx.set_option("kernel_mode", 3)
+        gpu_ctx.set_option("blas_builder", 0)
+    assert bits_equal(t1, t0) and bits_equal(c1, c0)
+    o = pyoracle.Oracle(sc)
+    o.build_own_blas()
+    ox, oy, sd = scenes.frame_uniforms(2)
+    o.set_frame((ox, oy), sd)
+    assert bits_equal(t1, o.render(mode=1, threads=8))
+
+
+def test_dynamic_scene_rebuilds_on_the_gpu(lbvh):
+    """RM:215-230 protocol: an object moves -> every buffer is re-uploaded -> the BVH is rebuilt; frames follow the scene."""
+    sc = scenes.mixed_test_scene(128, 80)
+    m, before, _ = render(lbvh, sc)
+    moved = sc.mesh_objects.copy()
+    mat = np.array(moved[0]["localToWorldMatrix"]).reshape(4, 4).T.copy()
+    mat[:3, 3] += (0.4, 0.3, -0.2)
+    moved[0]["localToWorldMatrix"] = mat.T.reshape(16)
+    m._meshObjectBuffer.SetData(moved)
+    sc2 = scenes.mixed_test_scene(128, 80)
+    sc2.mesh_objects = moved
+    lo, hi = scenes.mesh_bounds(moved, sc2.vertices, sc2.indices)
+    sc2.mesh_bvh = scenes.build_object_bvh(lo, hi)
+    m._meshObjectBVHBuffer.SetData(sc2.mesh_bvh)
+    m._frame = 0; m._currentSample = 0
+    m.OnRenderImage()
+    after = m._target.GetPixels()
+    m.OnDisable()
+    o = pyoracle.Oracle(sc2)
+    o.build_own_blas()
+    assert not bits_equal(after, before) and bits_equal(after, o.render(mode=1, threads=8))
+
+
+def test_bad_index_is_reported_like_the_host_builder(lbvh):
+    sc = scenes.mixed_test_scene(32, 24)
+    bad = sc.indices.copy()
+    bad[7] = len(sc.vertices) + 5
+    sc.indices = bad
+    m = RayTraceMaster(lbvh, sc)
+    with pytest.raises(UrtError) as e:
+        m.OnRenderImage()
+    assert e.value.code == 8 and "_Indices[7]" in str(e.value)
+    m.OnDisable()
+
+
+def test_c5_scene_preparation_under_10_ms(gpu_ctx):
+    """983,040 triangles in 12 MeshObjects: upload of the raw buffers + the whole GPU build, host wall clock."""
+    sc = scenes.CONFIGS["C5"](640, 360)
+    gpu_ctx.set_option("kernel_mode", 3)
+    gpu_ctx.set_option("blas_builder", 1)
+    try:
+        m = RayTraceMaster(gpu_ctx, sc)
+        m.OnRenderImage()                                        # first preparation also loads the build kernels
+        times = []
+        for _ in range(3):
+            m._vertexBuffer.SetData(np.ascontiguousarray(sc.vertices, np.float32))     # any SetData makes the scene stale (RM:250)
+            times.append(gpu_ctx.scene_info()["prepare_ms"])
+        info = gpu_ctx.scene_info()
+        img = m._target.GetPixels()
+        m.OnDisable()
+    finally:
+        gpu_ctx.set_option("blas_builder", 0)
+    print(f"C5 GPU scene preparation: {times} ms, {info}")
+    assert info["n_tris"] == 983040 and min(times) <= 10.0, times
+    m = RayTraceMaster(gpu_ctx, sc)                              # host SAH tree: same pixels
+    m.OnRenderImage()
+    ref = m._target.GetPixels()
+    host_ms = gpu_ctx.scene_info()["prepare_ms"]
+    m.OnDisable()
+    print(f"C5 host SAH scene preparation: {host_ms:.1f} ms")
+    assert bits_equal(img, ref)

@@ -20,7 +20,10 @@
 #include "../../include/urt.h"
 #include "blas_builder.h"
 #include "kernels.h"
+#include "lbvh.h"
 #include "urt_device.h"
+
+#include <chrono>
 
 using namespace urtd;
 
@@ -118,6 +121,10 @@ struct urt_context {
   // per dispatch), the AdditionShader blits that follow the dispatches are deferred with them and run in order after the
   // launch.  Everything else that could observe the images flushes first, so the in-order semantics of RM:806-820
   // stay exactly observable.
+  int opt_blas_builder = 0;                 // 0 = binned SAH on host threads (best trees), 1 = LBVH built on the GPU (dynamic scenes)
+  float last_prepare_ms = 0;                // host wall time of the last scene preparation (buffers -> device scene)
+  int n_scene_tris = 0;                     // triangles of the prepared scene
+  int scene_max_depth = 0;
   int opt_frames_per_launch = 0;            // 0 = auto (own stream: up to 16 frames / ~32 M pixels per launch; caller's stream: 1), 1 = off, 2..16
   uint64_t scene_epoch = 0;                 // bumps at every scene preparation
   struct PostOp { int kind; int frame; urt_handle tex; urt_handle dst; float sample; int first_row, row_stride; void* dense; };   // kind 0 = blit_add(tex@frame -> dst), 1 = pack_rows(tex -> dense)
@@ -228,26 +235,69 @@ int prepare_scene(urt_context* ctx) {
   int n_meshes = bm ? bm->count : 0;
   int n_spheres = bs ? bs->count : 0;
   std::vector<float> mats((size_t)(n_meshes + n_spheres) * 12);   // spheres first, then mesh objects
-  // meshes
-  BlasResult blas;
+  // meshes: the triangle BVH ("BLAS") of every MeshObject, by the host SAH builder or by the GPU LBVH builder
+  auto t_begin = std::chrono::steady_clock::now();
+  std::vector<int32_t> mesh_root_host;
+  int blas_max_depth = 0;
+  size_t n_blas_nodes = 0, n_tris = 0;
   if (n_meshes > 0) {
-    std::string err;
-    if (!build_blas(bm->host.data(), n_meshes, bv ? (const float*)bv->host.data() : nullptr, bv ? bv->count : 0,
-                    bi ? (const int32_t*)bi->host.data() : nullptr, bi ? bi->count : 0,
-                    bn ? (const float*)bn->host.data() : nullptr, bn ? bn->count : 0, blas, err, &ctx->blas_cache))
-      return fail(ctx, URT_ERR_SCENE, err);
     for (int m = 0; m < n_meshes; m++) {
       urt_MeshObject mo;
       std::memcpy(&mo, bm->host.data() + (size_t)m * URT_STRIDE_MESHOBJECT, sizeof mo);
       pack_material(mo.lighting, mats.data() + (size_t)(n_spheres + m) * 12);
     }
     const float4* p;
-    if ((rc = upload(ctx, blas.mesh_root, &p))) return rc; S.mesh_root = (const int32_t*)p;
+    if (ctx->opt_blas_builder == 1) {
+      // device copies of the buffers exactly as SetData delivered them; the whole build runs on the GPU (csrc/lbvh.hip)
+      std::vector<int32_t> offs((size_t)n_meshes), cnts((size_t)n_meshes);
+      for (int m = 0; m < n_meshes; m++) {
+        urt_MeshObject mo;
+        std::memcpy(&mo, bm->host.data() + (size_t)m * URT_STRIDE_MESHOBJECT, sizeof mo);
+        offs[(size_t)m] = mo.indices_offset; cnts[(size_t)m] = mo.indices_count;
+      }
+      void* raw = nullptr;
+      size_t b_mo = ((size_t)n_meshes * URT_STRIDE_MESHOBJECT + 255) & ~(size_t)255;
+      size_t b_v = bv ? (((size_t)bv->count * 12 + 255) & ~(size_t)255) : 0, b_i = bi ? (((size_t)bi->count * 4 + 255) & ~(size_t)255) : 0;
+      size_t b_n = bn ? (((size_t)bn->count * 12 + 255) & ~(size_t)255) : 0;
+      URT_HIP(ctx, hipMalloc(&raw, b_mo + b_v + b_i + b_n + 256));
+      char* rb = (char*)raw;
+      hipError_t e = hipMemcpy(rb, bm->host.data(), (size_t)n_meshes * URT_STRIDE_MESHOBJECT, hipMemcpyHostToDevice);
+      if (e == hipSuccess && bv) e = hipMemcpy(rb + b_mo, bv->host.data(), (size_t)bv->count * 12, hipMemcpyHostToDevice);
+      if (e == hipSuccess && bi) e = hipMemcpy(rb + b_mo + b_v, bi->host.data(), (size_t)bi->count * 4, hipMemcpyHostToDevice);
+      if (e == hipSuccess && bn) e = hipMemcpy(rb + b_mo + b_v + b_i, bn->host.data(), (size_t)bn->count * 12, hipMemcpyHostToDevice);
+      if (e != hipSuccess) { (void)hipFree(raw); return fail(ctx, URT_ERR_HIP, std::string("scene upload: ") + hipGetErrorString(e)); }
+      LbvhInput in;
+      in.mesh_objects = (const uint8_t*)rb; in.n_meshes = n_meshes;
+      in.vertices = bv ? (const float*)(rb + b_mo) : nullptr; in.n_vertices = bv ? bv->count : 0;
+      in.indices = bi ? (const int32_t*)(rb + b_mo + b_v) : nullptr; in.n_indices = bi ? bi->count : 0;
+      in.normals = bn ? (const float*)(rb + b_mo + b_v + b_i) : nullptr; in.n_normals = bn ? bn->count : 0;
+      in.h_offsets = offs.data(); in.h_counts = cnts.data(); in.leaf_max = get_blas_leaf_max();
+      LbvhOutput o;
+      std::string err;
+      rc = lbvh_build(in, ctx->stream, o, err);
+      (void)hipFree(raw);
+      if (rc) return fail(ctx, rc, err);
+      for (void* a : o.allocs) ctx->scene_allocs.push_back(a);
+      S.mesh_root = o.mesh_root; S.blas_nodes = o.nodes; S.tri_verts = o.tri_verts; S.tri_norms = o.tri_norms;
+      mesh_root_host = o.h_mesh_root; blas_max_depth = o.max_depth; n_blas_nodes = (size_t)o.n_nodes; n_tris = (size_t)o.n_tris;
+    } else {
+      BlasResult blas;
+      std::string err;
+      if (!build_blas(bm->host.data(), n_meshes, bv ? (const float*)bv->host.data() : nullptr, bv ? bv->count : 0,
+                      bi ? (const int32_t*)bi->host.data() : nullptr, bi ? bi->count : 0,
+                      bn ? (const float*)bn->host.data() : nullptr, bn ? bn->count : 0, blas, err, &ctx->blas_cache))
+        return fail(ctx, URT_ERR_SCENE, err);
+      if ((rc = upload(ctx, blas.mesh_root, &p))) return rc; S.mesh_root = (const int32_t*)p;
+      if ((rc = upload(ctx, blas.nodes, &p))) return rc; S.blas_nodes = p;
+      if ((rc = upload(ctx, blas.tri_verts, &p))) return rc; S.tri_verts = p;
+      if ((rc = upload(ctx, blas.tri_norms, &p))) return rc; S.tri_norms = p;
+      mesh_root_host = blas.mesh_root; blas_max_depth = blas.max_depth; n_blas_nodes = blas.nodes.size() / kBlasNodeFloats; n_tris = blas.tri_slot.size();
+    }
     {   // single-leaf MeshObjects: where their triangles sit in the LDS copy (kernels.hip k_sched prologue)
       std::vector<int32_t> small_first((size_t)n_meshes, -1);
       int n_small = 0;
       for (int m = 0; m < n_meshes; m++) {
-        int32_t r = blas.mesh_root[(size_t)m];
+        int32_t r = mesh_root_host[(size_t)m];
         if (r < 0 && r != (int32_t)0x80000000) { small_first[(size_t)m] = n_small; n_small += (int)((~(uint32_t)r) & 7u) + 1; }
       }
       if (n_small > 0 && n_small <= 64) {
@@ -255,9 +305,6 @@ int prepare_scene(urt_context* ctx) {
         S.mesh_small_first = (const int32_t*)p; S.n_small = n_small;
       }
     }
-    if ((rc = upload(ctx, blas.nodes, &p))) return rc; S.blas_nodes = p;
-    if ((rc = upload(ctx, blas.tri_verts, &p))) return rc; S.tri_verts = p;
-    if ((rc = upload(ctx, blas.tri_norms, &p))) return rc; S.tri_norms = p;
   }
   S.n_meshes = n_meshes;
   // spheres
@@ -291,15 +338,17 @@ int prepare_scene(urt_context* ctx) {
   if (lv + 1 > 32)
     return fail(ctx, URT_ERR_SCENE, "object-level BVH deeper than the reference's 32-entry traversal stack (RS:73-74)");
   ctx->tlas_stack = std::max(2, lv + 1);
-  ctx->blas_stack = std::max(2, blas.max_depth + 1);
-  ctx->n_blas_nodes = (int)std::min<size_t>(0x7fffffff, blas.nodes.size() / kBlasNodeFloats);
+  ctx->blas_stack = std::max(2, blas_max_depth + 1);
+  ctx->n_blas_nodes = (int)std::min<size_t>(0x7fffffff, n_blas_nodes);
+  ctx->n_scene_tris = (int)n_tris; ctx->scene_max_depth = blas_max_depth;
   // a ray with NaN components passes every slab test and walks the whole tree once: (nodes + leaves) trips per lane, and the
   // majority vote can make a lane wait a trip for every trip it runs; 8x that is a bound no correct traversal reaches
-  ctx->watchdog_steps = (unsigned int)std::min<size_t>(0x7fffffffu, 8 * (blas.nodes.size() / kBlasNodeFloats + blas.tri_slot.size()) + 4096);
+  ctx->watchdog_steps = (unsigned int)std::min<size_t>(0x7fffffffu, 8 * (n_blas_nodes + n_tris) + 4096);
   if ((size_t)(ctx->tlas_stack + ctx->blas_stack) * 64 * 4 * sizeof(int) > 150 * 1024)   // 4-wave workgroup; a CU has 160 KiB
     return fail(ctx, URT_ERR_SCENE, "traversal stacks exceed the LDS of a compute unit");
   ctx->scene_dirty = false;
   ctx->scene_epoch++;
+  ctx->last_prepare_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
   return URT_OK;
 }
 
@@ -1037,7 +1086,11 @@ int urt_set_option(urt_context* ctx, const char* name, int value) {
   if (!ctx) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "ctx is NULL");
   if (!name) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "option name is NULL");
   { (void)hipSetDevice(ctx->device); int rc = flush_pending(ctx); if (rc) return rc; }   // deferred frames run with the options they were dispatched under
-  if (std::strcmp(name, "frames_per_launch") == 0) {
+  if (std::strcmp(name, "blas_builder") == 0) {
+    if (value < 0 || value > 1) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "blas_builder must be 0 (host SAH) or 1 (GPU LBVH)");
+    if (value != ctx->opt_blas_builder) ctx->scene_dirty = true;
+    ctx->opt_blas_builder = value;
+  } else if (std::strcmp(name, "frames_per_launch") == 0) {
     if (value < 0 || value > kMaxFramesPerLaunch) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "frames_per_launch must be in [0, 16] (0 = auto)");
     ctx->opt_frames_per_launch = value;
   } else if (std::strcmp(name, "count_stats") == 0) ctx->opt_count_stats = value ? 1 : 0;
@@ -1183,6 +1236,37 @@ int urt_debug_blas_cache_stats(urt_context* ctx, uint64_t* out_reused, uint64_t*
   if (out_reused) *out_reused = ctx->blas_cache.hits;
   if (out_built) *out_built = ctx->blas_cache.builds;
   return URT_OK;
+}
+
+int urt_debug_scene_info(urt_context* ctx, int* out_n_nodes, int* out_n_tris, int* out_max_depth, float* out_prepare_ms) {
+  if (!ctx) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  URT_GUARD_BEGIN
+  URT_HIP(ctx, hipSetDevice(ctx->device));
+  if (ctx->scene_dirty) { int rc = flush_pending(ctx); if (rc) return rc; rc = prepare_scene(ctx); if (rc) return rc; }
+  if (out_n_nodes) *out_n_nodes = ctx->n_blas_nodes;
+  if (out_n_tris) *out_n_tris = ctx->n_scene_tris;
+  if (out_max_depth) *out_max_depth = ctx->scene_max_depth;
+  if (out_prepare_ms) *out_prepare_ms = ctx->last_prepare_ms;
+  return URT_OK;
+  URT_GUARD_END(ctx)
+}
+
+int urt_debug_read_scene_blas(urt_context* ctx, float* nodes, int32_t* tri_index, int32_t* mesh_root) {
+  if (!ctx) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  URT_GUARD_BEGIN
+  URT_HIP(ctx, hipSetDevice(ctx->device));
+  if (ctx->scene_dirty) { int rc = flush_pending(ctx); if (rc) return rc; rc = prepare_scene(ctx); if (rc) return rc; }
+  URT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const DevScene& S = ctx->ds;
+  if (nodes && ctx->n_blas_nodes > 0) URT_HIP(ctx, hipMemcpy(nodes, S.blas_nodes, (size_t)ctx->n_blas_nodes * kBlasNodeFloats * sizeof(float), hipMemcpyDeviceToHost));
+  if (mesh_root && S.n_meshes > 0) URT_HIP(ctx, hipMemcpy(mesh_root, S.mesh_root, (size_t)S.n_meshes * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (tri_index && ctx->n_scene_tris > 0) {
+    std::vector<float> tv((size_t)ctx->n_scene_tris * 12);
+    URT_HIP(ctx, hipMemcpy(tv.data(), S.tri_verts, tv.size() * sizeof(float), hipMemcpyDeviceToHost));
+    for (int k = 0; k < ctx->n_scene_tris; k++) std::memcpy(&tri_index[k], &tv[(size_t)k * 12 + 3], 4);     // index slot kept in v0.w
+  }
+  return URT_OK;
+  URT_GUARD_END(ctx)
 }
 
 int urt_debug_get_blas(float* nodes, int32_t* tri_index, int32_t* mesh_root, int32_t* mesh_first_tri) {

@@ -74,6 +74,21 @@ class Context:
     def reset_counters(self):
         self.check(self.lib.urt_reset_counters(self._h))
 
+    def scene_info(self) -> dict:
+        """Sizes of the current device scene's triangle BVH and the host time its preparation took (prepares it if stale)."""
+        nn, nt, md, ms = C.c_int(), C.c_int(), C.c_int(), C.c_float()
+        self.check(self.lib.urt_debug_scene_info(self._h, C.byref(nn), C.byref(nt), C.byref(md), C.byref(ms)))
+        return {"n_nodes": nn.value, "n_tris": nt.value, "max_depth": md.value, "prepare_ms": ms.value}
+
+    def read_scene_blas(self, n_meshes: int):
+        """(nodes[n,16], tri_index[n_tris], mesh_root[n_meshes]) of the current device scene, read back from the GPU."""
+        info = self.scene_info()
+        nodes = np.zeros((info["n_nodes"], 16), dtype=np.float32)
+        tri = np.zeros(info["n_tris"], dtype=np.int32)
+        root = np.zeros(n_meshes, dtype=np.int32)
+        self.check(self.lib.urt_debug_read_scene_blas(self._h, nodes.ctypes.data_as(C.c_void_p), tri.ctypes.data_as(C.c_void_p), root.ctypes.data_as(C.c_void_p)))
+        return nodes, tri, root, info
+
 
 class _GroupLib:
     """Maps the per-context entry points onto their urt_group_* counterparts, so that ComputeBuffer / RenderTexture /
