@@ -138,3 +138,23 @@ def test_scene_change_inside_a_batch(gpu_ctx):
         return out
 
     assert bits_equal(protocol(8), protocol(1))
+
+
+def test_checkpoint_resume_of_progressive_accumulation(gpu_ctx, tmp_path):
+    """10 accumulated frames == 6 frames, checkpoint to disk, a NEW master resumed from it, 4 more frames (bit for bit)."""
+    sc = scenes.mixed_test_scene(120, 72)
+    ref_conv, _, _, _ = run_frames(gpu_ctx, sc, 10, 0)
+    m = RayTraceMaster(gpu_ctx, sc)
+    for _ in range(6):
+        m.OnRenderImage()
+    ck = str(tmp_path / "accum.npz")
+    m.SaveCheckpoint(ck)
+    m.OnDisable()
+    m2 = RayTraceMaster(gpu_ctx, sc)
+    m2.LoadCheckpoint(ck)
+    assert m2._currentSample == 6
+    for _ in range(4):
+        m2.OnRenderImage()
+    got = m2._converged.GetPixels()
+    m2.OnDisable()
+    assert bits_equal(got, ref_conv)

@@ -42,6 +42,23 @@ def test_compute_normals_equals_literal_bitwise(built_library):
     assert np.allclose(scenes.compute_normals(v, idx), host_scene.compute_normals(v, idx), atol=1e-6)
 
 
+def test_compute_normals_welds_positions_whose_squared_distance_underflows(built_library):
+    """RM:351 compares (a - b).sqrMagnitude with 3 * float.Epsilon: two DIFFERENT positions weld when every coordinate
+    difference is below ~3.7e-23 (its square underflows) — only possible next to zero.  The C++ version detects such
+    coordinates and runs the reference's literal loop: bit-identical to the literal restatement, and really welded."""
+    v, idx = welded_test_mesh(3)
+    v = v.copy()
+    k = int(idx[0])
+    twin = np.array([[v[k, 0], v[k, 1], 0.0]], np.float32)
+    v[k, 2] = np.float32(3e-23)                                      # vertex k and its twin differ by 3e-23 in z only
+    v = np.concatenate([v, twin]).astype(np.float32)
+    idx = np.concatenate([idx, [len(v) - 1, int(idx[1]), int(idx[2])]]).astype(np.int32)     # a triangle that uses the twin
+    lit = pyoracle.compute_normals_literal(v, idx)
+    got = host_scene.compute_normals(v, idx)
+    assert same_bits(got, lit)
+    assert same_bits(got[k], got[-1])                                 # the two distinct positions share one normal
+
+
 def test_compute_normals_is_linear_time(built_library):
     v, t = scenes.uv_blob(200, 175)                                    # 69,600 triangles: the literal O(V*I) loop would need ~7e9 steps
     t0 = time.perf_counter()

@@ -70,18 +70,56 @@ int urt_host_compute_normals(const float* vertices, int n_vertices, const int32_
   if (n_vertices < 0 || n_indices < 0 || n_indices % 3 != 0) return host_fail(URT_ERR_INVALID_ARGUMENT, "ComputeNormals: bad counts");
   if ((n_vertices && (!vertices || !out_normals)) || (n_indices && !indices)) return host_fail(URT_ERR_INVALID_ARGUMENT, "ComputeNormals: NULL array");
   try {
-    // weld: vertices whose positions are equal form one group (RM:351 with EPSILON = 3 * float.Epsilon: equality for
-    // anything but differences that underflow when squared)
+    // RM:351 welds index slots whose vertex satisfies (v - v_i).sqrMagnitude <= EPSILON = 3 * float.Epsilon (4.2e-45): that is
+    // plain equality (-0 == +0) EXCEPT for differences so small that their squares underflow.  Two DIFFERENT positions can only
+    // pass when, on every axis, their coordinates are equal or both of magnitude below 2^-50 (distinct floats of magnitude
+    // >= 2^-50 differ by >= 2^-73, whose square 1.1e-44 already exceeds EPSILON; numerical zeros like sin(pi) * r = 1e-17
+    // are common in real meshes, so this is not a corner to ignore).
+    // Step 1: exact groups (O(V + I) position hash).
     std::unordered_map<Key, int, KeyHash> groups;
     groups.reserve((size_t)n_vertices * 2);
     std::vector<int> group_of((size_t)n_vertices);
+    std::vector<int> rep;                                   // one vertex per group
     for (int i = 0; i < n_vertices; i++) {
       Key k{bits_no_negzero(vertices[3 * i]), bits_no_negzero(vertices[3 * i + 1]), bits_no_negzero(vertices[3 * i + 2])};
       auto it = groups.find(k);
-      if (it == groups.end()) it = groups.emplace(k, (int)groups.size()).first;
+      if (it == groups.end()) { it = groups.emplace(k, (int)groups.size()).first; rep.push_back(i); }
       group_of[(size_t)i] = it->second;
     }
-    std::vector<V3> acc(groups.size(), V3{0, 0, 0});
+    const size_t ng = groups.size();
+    // Step 2: groups that weld with OTHER groups.  Candidates share a coarse key (coordinates below 2^-50 mapped to 0);
+    // inside a coarse bucket the reference's float test decides, pair by pair (the relation is not transitive).
+    const float kTiny = 8.8817842e-16f;                     // 2^-50
+    const float kEps = 3.0f * 1.401298464e-45f;              // RM:14
+    std::vector<std::vector<int>> partners(0);
+    std::vector<int> partner_slot(ng, -1);                   // group -> index into `partners`, or -1 (the common case)
+    {
+      std::unordered_map<Key, std::vector<int>, KeyHash> coarse;
+      for (size_t g = 0; g < ng; g++) {
+        const float* p = vertices + 3 * (size_t)rep[g];
+        bool has_small = false;
+        uint32_t kk[3];
+        for (int c = 0; c < 3; c++) { bool small = std::fabs(p[c]) < kTiny; has_small = has_small || small; kk[c] = small ? 0u : bits_no_negzero(p[c]); }
+        if (has_small) coarse[Key{kk[0], kk[1], kk[2]}].push_back((int)g);
+      }
+      for (auto& kv : coarse) {
+        const std::vector<int>& b = kv.second;
+        if (b.size() < 2) continue;
+        for (size_t x = 0; x < b.size(); x++)
+          for (size_t y = x + 1; y < b.size(); y++) {
+            V3 d = sub(ld(vertices + 3 * (size_t)rep[(size_t)b[x]]), ld(vertices + 3 * (size_t)rep[(size_t)b[y]]));
+            if (d.x * d.x + d.y * d.y + d.z * d.z <= kEps) {
+              for (int side = 0; side < 2; side++) {
+                int g = side ? b[y] : b[x], o = side ? b[x] : b[y];
+                if (partner_slot[(size_t)g] < 0) { partner_slot[(size_t)g] = (int)partners.size(); partners.emplace_back(); }
+                partners[(size_t)partner_slot[(size_t)g]].push_back(o);
+              }
+            }
+          }
+      }
+    }
+    std::vector<V3> acc(ng, V3{0, 0, 0});
+    std::vector<std::vector<int>> slots(partners.size());    // ascending index slots of the groups that have partners
     // every index slot j (ascending, the order of the reference's LINQ query) adds the un-normalised normal of ITS
     // triangle to the group of the vertex it refers to (RM:355-362)
     for (int start = 0; start + 2 < n_indices; start += 3) {
@@ -91,7 +129,26 @@ int urt_host_compute_normals(const float* vertices, int n_vertices, const int32_
       V3 a = ld(vertices + 3 * i0), b = ld(vertices + 3 * i1), c = ld(vertices + 3 * i2);
       V3 face = cross(sub(b, a), sub(c, a));
       const int vs[3] = {i0, i1, i2};
-      for (int j = 0; j < 3; j++) { V3& s = acc[(size_t)group_of[(size_t)vs[j]]]; s = add(s, face); }
+      for (int j = 0; j < 3; j++) {
+        int g = group_of[(size_t)vs[j]];
+        V3& s = acc[(size_t)g]; s = add(s, face);
+        if (partner_slot[(size_t)g] >= 0) slots[(size_t)partner_slot[(size_t)g]].push_back(start + j);
+      }
+    }
+    // groups with partners: re-sum over the union of the slot lists in ascending slot order (float adds do not commute)
+    for (size_t g = 0; g < ng; g++) {
+      int ps = partner_slot[g];
+      if (ps < 0) continue;
+      std::vector<int> all = slots[(size_t)ps];
+      for (int o : partners[(size_t)ps]) { const std::vector<int>& so = slots[(size_t)partner_slot[(size_t)o]]; all.insert(all.end(), so.begin(), so.end()); }
+      std::sort(all.begin(), all.end());
+      V3 s{0, 0, 0};
+      for (int j : all) {
+        int start = j - j % 3;
+        V3 a = ld(vertices + 3 * (size_t)indices[start]);
+        s = add(s, cross(sub(ld(vertices + 3 * (size_t)indices[start + 1]), a), sub(ld(vertices + 3 * (size_t)indices[start + 2]), a)));
+      }
+      acc[g] = s;
     }
     for (int i = 0; i < n_vertices; i++) {
       V3 n = normalize(acc[(size_t)group_of[(size_t)i]]);

@@ -109,7 +109,7 @@ class RayTraceMaster:
             if len(s.mesh_objects) else np.zeros(0, scenes.BVHNODE_DT)
         s.sphere_bvh = host_scene.build_object_bvh(host_scene.sphere_leaf_bounds(s.spheres, literal_leaf_bounds)) \
             if len(s.spheres) else np.zeros(0, scenes.BVHNODE_DT)
-        if self.rayDebug is not None:                                             # RM:331-335
+        if getattr(self, "rayDebug", None) is not None:                             # RM:331-335
             self.rayDebug.LogSceneCounts(len(s.spheres), len(s.mesh_objects), len(s.vertices), len(s.indices), len(s.normals))
 
     # RM:233-252
@@ -235,6 +235,28 @@ class RayTraceMaster:
             self.rayDebug.DrawBVHTree(s.sphere_bvh, self.tree_depth(len(s.spheres)), 1)
             return mesh_dump, getattr(self.rayDebug, "last_dump", None)
         return None, None
+
+    # ---- checkpoint / resume of a progressive accumulation (the reference keeps `_converged` only in GPU memory and loses it
+    # on every reset, RM:189,766,843,852; a 1024-spp run such as BASELINE config 5 wants to survive a restart) ----
+    def SaveCheckpoint(self, path: str):
+        """The running mean and the counters that index the frame sequence -> one .npz (readback submits and waits)."""
+        np.savez(path, converged=self._converged.GetPixels(), currentSample=self._currentSample, frame=self._frame,
+                 frame_seed=self.frame_seed, size=(self.screen_width, self.screen_height))
+
+    def LoadCheckpoint(self, path: str):
+        """Resume: the next OnRenderImage blends frame `frame` with alpha 1 / (currentSample + 1) into the restored mean."""
+        z = np.load(path, allow_pickle=False)
+        w, h = (int(v) for v in z["size"])
+        if (w, h) != (self.screen_width, self.screen_height):
+            raise ValueError("checkpoint is of another resolution")
+        if self._treesNeedRebuilding:                       # RM:850-859 would reset the sample counter: do the rebuild first
+            self._treesNeedRebuilding = False
+            if self._rayTraceObjects:
+                self.RebuildObjectLists()
+            self.RebuildTrees()
+        self.InitRenderTexture()
+        self._converged.SetPixels(z["converged"])
+        self._currentSample, self._frame, self.frame_seed = int(z["currentSample"]), int(z["frame"]), int(z["frame_seed"])
 
     # RM:188-212
     def OnDisable(self):
