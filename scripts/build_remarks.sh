@@ -21,7 +21,8 @@ for line in open('/tmp/urt_remarks.log'):
         cur[k] = v
 for r in rows:
     name = subprocess.run(['c++filt', r['name']], capture_output=True, text=True).stdout.strip()
-    name = re.sub(r'^void \(anonymous namespace\)::', '', name).split('(')[0]
+    if 'rocprim' in name: continue                       # library sort / scan kernels of the GPU BVH build
+    name = re.sub(r'^(void )?\(anonymous namespace\)::', '', name).split('(')[0]
     print(f"{name:45s} VGPR {r.get('VGPRs','?'):>4} AGPR {r.get('AGPRs','?'):>3} SGPR {r.get('TotalSGPRs','?'):>4} scratch {r.get('ScratchSize [bytes/lane]','?'):>4} B/lane  "
           f"spill v{r.get('VGPRs Spill','?')} s{r.get('SGPRs Spill','?')}  occupancy {r.get('Occupancy [waves/SIMD]','?')}  LDS {r.get('LDS Size [bytes/block]','?')}")
 PY
