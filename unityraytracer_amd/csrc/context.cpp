@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "../../include/urt.h"
+#include "../../include/urt_math.h"
 #include "blas_builder.h"
 #include "kernels.h"
 #include "lbvh.h"
@@ -197,10 +198,32 @@ const Buffer* bound_buffer(urt_context* ctx, int slot) {
   return &it->second;
 }
 
-void pack_material(const urt_RayTraceParams& m, float* dst12) {
-  dst12[0] = m.color_albedo[0]; dst12[1] = m.color_albedo[1]; dst12[2] = m.color_albedo[2]; dst12[3] = m.smoothness;
-  dst12[4] = m.color_specular[0]; dst12[5] = m.color_specular[1]; dst12[6] = m.color_specular[2]; dst12[7] = 0;
-  dst12[8] = m.emission[0]; dst12[9] = m.emission[1]; dst12[10] = m.emission[2]; dst12[11] = 0;
+// Everything Shade (RS:388-419) derives from the material ALONE is evaluated here, once per material, with the normative
+// arithmetic of include/urt_math.h in the shader's own operation order (the same functions the oracle evaluates per hit, so the
+// bits are the same): the clamped albedo, the two normalised roulette chances and their sum, the Phong exponent
+// alpha = pow(1000, smoothness^2), 1/(alpha+1), (alpha+2)/(alpha+1) and the two energy factors (1/chance) * colour.
+// Per hit the kernel then loads 64 bytes and skips two dot products, a pow and six IEEE divisions.
+//   [0] (1/diffChance) * albedo', specChance      [1] (1/specChance) * specular, specChance + diffChance
+//   [2] emission, diffChance                       [3] alpha, 1/(alpha+1), (alpha+2)/(alpha+1), 0
+constexpr int kMatFloats = 16;
+void pack_material(const urt_RayTraceParams& m, float* dst) {
+  using namespace urt;
+  v3 albedo = mk3(m.color_albedo[0], m.color_albedo[1], m.color_albedo[2]);
+  v3 spec = mk3(m.color_specular[0], m.color_specular[1], m.color_specular[2]);
+  albedo = vmin3(mk3(1.0f, 1.0f, 1.0f) - spec, albedo);                          // RS:390
+  const float third = 1.0f / 3.0f;
+  float specChance = dot(spec, mk3(third, third, third));                        // RS:391-392
+  float diffChance = dot(albedo, mk3(third, third, third));
+  float sum = specChance + diffChance;                                           // RS:393-395
+  specChance /= sum;
+  diffChance /= sum;
+  float alpha = f_pow(1000.0f, m.smoothness * m.smoothness);                     // RS:401
+  v3 ks = (1.0f / specChance) * spec;                                            // RS:405
+  v3 kd = (1.0f / diffChance) * albedo;                                          // RS:411
+  dst[0] = kd.x; dst[1] = kd.y; dst[2] = kd.z; dst[3] = specChance;
+  dst[4] = ks.x; dst[5] = ks.y; dst[6] = ks.z; dst[7] = specChance + diffChance;
+  dst[8] = m.emission[0]; dst[9] = m.emission[1]; dst[10] = m.emission[2]; dst[11] = diffChance;
+  dst[12] = alpha; dst[13] = 1.0f / (alpha + 1.0f); dst[14] = (alpha + 2) / (alpha + 1); dst[15] = 0.0f;   // RS:104, 404
 }
 
 int heap_levels(int n) { int l = 0; while (n > 0) { l++; n >>= 1; } return l; }   // floor(log2 n) + 1
@@ -234,7 +257,13 @@ int prepare_scene(urt_context* ctx) {
   int rc;
   int n_meshes = bm ? bm->count : 0;
   int n_spheres = bs ? bs->count : 0;
-  std::vector<float> mats((size_t)(n_meshes + n_spheres) * 12);   // spheres first, then mesh objects
+  std::vector<float> mats((size_t)(n_meshes + n_spheres + 1) * kMatFloats);   // spheres first, then mesh objects, then the ground plane
+  {
+    urt_RayTraceParams ground{};                                                 // RS:164-170: hard-coded material of the y = 0 plane
+    ground.color_albedo[0] = 0.5f; ground.color_albedo[1] = 0.3f; ground.color_albedo[2] = 0.15f;
+    ground.smoothness = 0.3f;
+    pack_material(ground, mats.data() + (size_t)(n_meshes + n_spheres) * kMatFloats);
+  }
   // meshes: the triangle BVH ("BLAS") of every MeshObject, by the host SAH builder or by the GPU LBVH builder
   auto t_begin = std::chrono::steady_clock::now();
   std::vector<int32_t> mesh_root_host;
@@ -244,7 +273,7 @@ int prepare_scene(urt_context* ctx) {
     for (int m = 0; m < n_meshes; m++) {
       urt_MeshObject mo;
       std::memcpy(&mo, bm->host.data() + (size_t)m * URT_STRIDE_MESHOBJECT, sizeof mo);
-      pack_material(mo.lighting, mats.data() + (size_t)(n_spheres + m) * 12);
+      pack_material(mo.lighting, mats.data() + (size_t)(n_spheres + m) * kMatFloats);
     }
     const float4* p;
     if (ctx->opt_blas_builder == 1) {
@@ -315,7 +344,7 @@ int prepare_scene(urt_context* ctx) {
       std::memcpy(&sp, bs->host.data() + (size_t)i * URT_STRIDE_SPHERE, sizeof sp);
       pr[4 * (size_t)i] = sp.position[0]; pr[4 * (size_t)i + 1] = sp.position[1]; pr[4 * (size_t)i + 2] = sp.position[2];
       pr[4 * (size_t)i + 3] = sp.radius;
-      pack_material(sp.lighting, mats.data() + (size_t)i * 12);
+      pack_material(sp.lighting, mats.data() + (size_t)i * kMatFloats);
     }
     const float4* p;
     if ((rc = upload(ctx, pr, &p))) return rc; S.sphere_pr = p;
@@ -338,6 +367,7 @@ int prepare_scene(urt_context* ctx) {
   if (lv + 1 > 32)
     return fail(ctx, URT_ERR_SCENE, "object-level BVH deeper than the reference's 32-entry traversal stack (RS:73-74)");
   ctx->tlas_stack = std::max(2, lv + 1);
+  if (n_blas_nodes >= (1u << 26)) return fail(ctx, URT_ERR_SCENE, "triangle BVH larger than 2^26 nodes (4 GiB)");   // kernels address nodes by 32-bit byte offsets
   ctx->blas_stack = std::max(2, blas_max_depth + 1);
   ctx->n_blas_nodes = (int)std::min<size_t>(0x7fffffff, n_blas_nodes);
   ctx->n_scene_tris = (int)n_tris; ctx->scene_max_depth = blas_max_depth;

@@ -49,6 +49,9 @@ struct HitRec {
 };
 
 __device__ __forceinline__ v3 xyz(float4 q) { return mk3(q.x, q.y, q.z); }
+// wave64 vote straight from the lane predicate (HIP's wballot(int) first materialises the predicate as 0/1 in a VGPR and
+// compares it again: two VALU instructions per vote, and the scheduler votes several times per trip)
+__device__ __forceinline__ unsigned long long wballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ int as_int(float f) { return __builtin_bit_cast(int, f); }
 __device__ __forceinline__ float as_float(int i) { return __builtin_bit_cast(float, i); }
 
@@ -194,7 +197,8 @@ template <bool COUNT>
 __device__ __forceinline__ int32_t blas_node_step(const DevScene& S, int32_t cur, const BlasRay& R, float tbest, int* stk, int& sp,
                                                   LocalCounters& lc) {
   if (COUNT) lc.blas_nodes++;
-  const float4* n = S.blas_nodes + 4 * (size_t)cur;
+  // uniform base + 32-bit byte offset (the node array is < 4 GiB: checked on the host), so the load needs no 64-bit address math
+  const float4* n = (const float4*)((const char*)S.blas_nodes + ((uint32_t)cur << 6));
   float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
   return blas_node_eval(q0, q1, q2, q3, R, tbest, stk, sp);
 }
@@ -288,8 +292,9 @@ __device__ __forceinline__ HitRec trace(const DevScene& S, v3 o, v3 d, int* tl, 
 // ---------------------------------------------------------------------------------------------------
 // Shade — RS:386-428 (+ SampleHemisphere RS:103-111, GetTangentSpace RS:89-100, sky lookup A.11)
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ v3 sample_hemisphere(v3 normal, float alpha, float& seed, float px, float py) {
-  float cosTheta = f_pow(rand_next(seed, px, py), 1.0f / (alpha + 1.0f));
+// inv_alpha1 = 1 / (alpha + 1) (RS:104), precomputed per material on the host (context.cpp pack_material); 0.5 for the diffuse lobe
+__device__ __forceinline__ v3 sample_hemisphere(v3 normal, float inv_alpha1, float& seed, float px, float py) {
+  float cosTheta = f_pow(rand_next(seed, px, py), inv_alpha1);
   float sinTheta = f_sqrt(1.0f - cosTheta * cosTheta);
   float phi = (2.0f * kPI) * rand_next(seed, px, py);
   float sp, cp; f_sincos(phi, sp, cp);
@@ -339,60 +344,50 @@ __device__ __forceinline__ bool shade_surface(const DevScene& S, const HitRec& h
   v3 s;
   {
     v3 pos = madd(h.t, d, o);
-    v3 n, albedo, spec, emission; float smooth;
+    v3 n;
+    int mat;                                   // one material table: spheres, then mesh objects, then the ground plane
     if (h.kind() == 1) {                       // RS:164-170
       if (COUNT) lc.hit_ground++;
       n = mk3(0, 1, 0);
-      albedo = mk3(0.5f, 0.3f, 0.15f); spec = mk3(0, 0, 0); emission = mk3(0, 0, 0); smooth = 0.3f;
-    } else {
-      // one material table: spheres first, then mesh objects (an integer select, no pointer select)
-      int mat;
-      if (h.kind() == 2) {                     // RS:192-194
-        if (COUNT) lc.hit_sphere++;
-        n = normalize(pos - xyz(S.sphere_pr[h.id()]));
-        mat = h.id();
-      } else {                               // RS:259-264
-        if (COUNT) lc.hit_tri++;
-        const float4* tn = S.tri_norms + 3 * (size_t)h.id();
-        v3 n0 = xyz(tn[0]), n1 = xyz(tn[1]), n2 = xyz(tn[2]);
-        float w = 1.0f - h.u - h.v;
-        n = normalize((n0 * w) + (n1 * h.u) + (n2 * h.v));
-        mat = S.n_spheres + as_int(S.tri_verts[3 * (size_t)h.id() + 1].w);
-      }
-      const float4* m = S.materials + 3 * (size_t)mat;
-      float4 m0 = m[0], m1 = m[1], m2 = m[2];
-      albedo = xyz(m0); smooth = m0.w; spec = xyz(m1); emission = xyz(m2);
+      mat = S.n_spheres + S.n_meshes;
+    } else if (h.kind() == 2) {                // RS:192-194
+      if (COUNT) lc.hit_sphere++;
+      n = normalize(pos - xyz(S.sphere_pr[h.id()]));
+      mat = h.id();
+    } else {                                   // RS:259-264
+      if (COUNT) lc.hit_tri++;
+      const float4* tn = S.tri_norms + 3 * (size_t)h.id();
+      v3 n0 = xyz(tn[0]), n1 = xyz(tn[1]), n2 = xyz(tn[2]);
+      float w = 1.0f - h.u - h.v;
+      n = normalize((n0 * w) + (n1 * h.u) + (n2 * h.v));
+      mat = S.n_spheres + as_int(S.tri_verts[3 * (size_t)h.id() + 1].w);
     }
-    albedo = vmin3(mk3(1.0f, 1.0f, 1.0f) - spec, albedo);
-    const float third = 1.0f / 3.0f;
-    float specChance = dot(spec, mk3(third, third, third));
-    float diffChance = dot(albedo, mk3(third, third, third));
-    float sum = specChance + diffChance;
-    specChance /= sum;
-    diffChance /= sum;
+    // what RS:390-395, 401, 404-405, 411 derive from the material alone comes precomputed (context.cpp pack_material)
+    const float4* m = S.materials + 4 * (size_t)mat;
+    float4 m0 = m[0], m1 = m[1], m2 = m[2], m3 = m[3];
+    float specChance = m0.w, bothChances = m1.w, diffChance = m2.w;
     float roulette = rand_next(seed, px, py);
     // RS:399-418.  The specular and the diffuse branch both end in SampleHemisphere: lanes of one wave take either, so the
-    // branch-specific inputs (lobe axis, Phong alpha) are selected first and the long common part runs ONCE for both kinds
+    // branch-specific inputs (lobe axis, 1/(alpha+1)) are selected first and the long common part runs ONCE for both kinds
     // of lane.  Per lane the operations and their order are those of the two-branch form.
     bool is_spec = roulette < specChance;
-    bool is_diff = !is_spec && diffChance > 0 && roulette < specChance + diffChance;
+    bool is_diff = !is_spec && diffChance > 0 && roulette < bothChances;
     if (is_spec || is_diff) {
-      float alpha = 1.0f;
+      float inv_alpha1 = 0.5f;                 // diffuse: alpha = 1 (RS:410)
       v3 axis = n;
-      if (is_spec) { alpha = f_pow(1000.0f, smooth * smooth); axis = reflect(d, n); }
+      if (is_spec) { inv_alpha1 = m3.y; axis = reflect(d, n); }
       o = madd(0.001f, n, pos);
-      d = sample_hemisphere(axis, alpha, seed, px, py);
+      d = sample_hemisphere(axis, inv_alpha1, seed, px, py);
       if (is_spec) {
-        float f = (alpha + 2) / (alpha + 1);
-        float sd = f_saturate(dot(n, d) * f);
-        energy = energy * (((1.0f / specChance) * spec) * sd);
+        float sd = f_saturate(dot(n, d) * m3.z);
+        energy = energy * (xyz(m1) * sd);
       } else {
-        energy = energy * ((1.0f / diffChance) * albedo);
+        energy = energy * xyz(m0);
       }
     } else {
       energy = mk3(0, 0, 0);
     }
-    s = emission;
+    s = xyz(m2);
   }
   result = result + e0 * s;
   return any_nonzero(energy);
@@ -474,12 +469,12 @@ static_assert(__builtin_offsetof(FrameUniforms, invp) == 64 && __builtin_offseto
 // always one: a wave's refill straddles two frames only at a frame boundary of the launch).
 template <typename F>
 __device__ __forceinline__ void for_each_frame(bool pred, int frame, F&& body) {
-  unsigned long long todo = __ballot(pred);
+  unsigned long long todo = wballot(pred);
   while (todo) {
     int f = __builtin_amdgcn_readlane(frame, __builtin_ctzll(todo));
     bool mine = pred && frame == f;
     body(f, mine);
-    todo &= ~__ballot(mine);
+    todo &= ~wballot(mine);
   }
 }
 
@@ -625,7 +620,7 @@ __device__ __forceinline__ bool wave_fetch_pixels(const FrameParams& P, unsigned
   unsigned int shard = wc.shard;
   if (base + n >= own) {   // this shard is (now) dry: every lane looks at one counter, the wave moves to the next shard with work
     unsigned int seen = __hip_atomic_load(next + lane * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned long long avail = __ballot(seen < shard_slots(ntiles, (unsigned int)lane, G)) & ~(1ull << shard);
+    unsigned long long avail = wballot(seen < shard_slots(ntiles, (unsigned int)lane, G)) & ~(1ull << shard);
     if (!avail) {
       exhausted = true;    // counters only grow, so this is final
     } else {
@@ -667,7 +662,7 @@ __global__ __launch_bounds__(256) void k_persist(DevScene S, FrameParams P, floa
   float px = 0, py = 0, seed = 0;
   v3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), energy = mk3(0, 0, 0), res = mk3(0, 0, 0), avg = mk3(0, 0, 0);
   for (;;) {
-    unsigned long long dead = __ballot(!alive);
+    unsigned long long dead = wballot(!alive);
     int ndead = __popcll(dead);
     if (!exhausted && ndead >= P.refill_min) {
       bool got = wave_fetch_pixels(P, dead, !alive, next, ntiles, wc, exhausted, x, y);
@@ -682,7 +677,7 @@ __global__ __launch_bounds__(256) void k_persist(DevScene S, FrameParams P, floa
         camera_ray<kPOffAfterScene>(P, x, y, seed, o, d);
       }
     }
-    if (__ballot(alive) == 0) {
+    if (wballot(alive) == 0) {
       if (exhausted) break;
       continue;                       // every fetched slot fell outside the region: fetch again
     }
@@ -903,12 +898,12 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
 #ifdef URT_STAMPS
     if (exhausted && !t_dry) t_dry = wall_clock64();
 #endif
-    unsigned long long mD = __ballot(st == ST_DEAD);
+    unsigned long long mD = wballot(st == ST_DEAD);
     int nD = __popcll(mD);
-    int nB = __popcll(__ballot(st == ST_BLAS));
-    int nS = __popcll(__ballot(st == ST_SHADE));
-    int nK = __popcll(__ballot(st == ST_SKY));
-    int nF = __popcll(__ballot(st == ST_FRONT || st == ST_RESUME));
+    int nB = __popcll(wballot(st == ST_BLAS));
+    int nS = __popcll(wballot(st == ST_SHADE));
+    int nK = __popcll(wballot(st == ST_SKY));
+    int nF = __popcll(wballot(st == ST_FRONT || st == ST_RESUME));
     // ---- refill dead lanes from the frame's work counter (one atomic per refill): when enough lanes are dead, or when
     // nothing else is left to run ----
     if (!exhausted && nD > 0 && (nD >= P.refill_min || nB + nS + nK + nF == 0)) {
@@ -922,8 +917,8 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
           camera_ray_frame<kTOffAfterParams>(f, P, x, y, true, seed, o, d);
         }
       });
-      nF = __popcll(__ballot(st == ST_FRONT || st == ST_RESUME));
-      nD = __popcll(__ballot(st == ST_DEAD));
+      nF = __popcll(wballot(st == ST_FRONT || st == ST_RESUME));
+      nD = __popcll(wballot(st == ST_DEAD));
     }
     bool can_refill = !exhausted && nD >= P.refill_min;
     if (++wave_iters > kWatchdogIters) { watchdog = true; break; }   // an exit every wave reaches, whatever the data
@@ -961,7 +956,7 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
 #endif
     if (phase == ST_FRONT) {
       // ---------------- FRONT / RESUME: Trace() up to the next triangle-BVH visit (RS:364-383) ----------------
-      wave_rays += (unsigned int)__popcll(__ballot(st == ST_FRONT));     // Trace() invocations (RS:454), counted per wave
+      wave_rays += (unsigned int)__popcll(wballot(st == ST_FRONT));     // Trace() invocations (RS:454), counted per wave
       if (st == ST_FRONT || st == ST_RESUME) {
         sp = 0;
         int check = cs & 0xff; bool seen = (cs >> 8) != 0;
@@ -982,11 +977,11 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
         do cur = blas_node_step_top<COUNT>(top, cur, R, best.t, bl, sp, lc); while (cur >= 0 && cur < P.top_nodes);
       }
       bool active = mine && cur != kBlasDone;
-      unsigned int steps = 0;
+      int budget = (int)min(P.watchdog_steps, 0x7fffffffu);     // trips left before the watchdog ends this phase (counted down: no kernel argument in the loop)
       for (;;) {
-        unsigned long long mA = __ballot(active);
+        unsigned long long mA = wballot(active);
         if (__popcll(mA) < exit_below) break;
-        if (++steps > P.watchdog_steps) { watchdog = true; break; }
+        if (--budget < 0) { watchdog = true; break; }
 #ifdef URT_STAMPS
         ph_trips[3]++; ph_lanes[3] += (unsigned long long)__popcll(mA);
         if (exhausted) { dr_trips[3]++; dr_lanes3 += (unsigned long long)__popcll(mA); }
@@ -994,7 +989,7 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
         // majority vote: this trip runs EITHER the interior-node step OR the leaf step, for the lanes that hold that kind
         // of cursor (the others wait one trip) — so a trip costs one of the two bodies, not their sum.
         bool interior = active && cur >= 0;
-        int nI = __popcll(__ballot(interior));
+        int nI = __popcll(wballot(interior));
         int nL = __popcll(mA) - nI;
         if (nI >= nL) {
           if (interior) cur = blas_node_step<COUNT>(S, cur, R, best.t, bl, sp, lc);
@@ -1091,7 +1086,7 @@ __device__ __forceinline__ int pool_select(const int* stt, int* list, int lo, in
     int slot = j * 64 + lane;
     int v = stt[slot];
     bool m = v >= lo && v <= hi;
-    unsigned long long b = __ballot(m);
+    unsigned long long b = wballot(m);
     if (m) list[base + __popcll(b & below)] = slot;
     base += __popcll(b);
   }
@@ -1140,11 +1135,11 @@ __global__ __launch_bounds__(64) void k_pool(DevScene S, FrameParams P, float4* 
 #pragma unroll
     for (int j = 0; j < K; j++) {
       int v = stt[j * 64 + lane];
-      nFree += __popcll(__ballot(v == PS_FREE));
-      nFront += __popcll(__ballot(v == PS_FRONT || v == PS_RESUME));
-      nNew += __popcll(__ballot(v == PS_BLAS));
-      nPin += __popcll(__ballot(v == PS_PINNED));
-      nShade += __popcll(__ballot(v == PS_SHADE));
+      nFree += __popcll(wballot(v == PS_FREE));
+      nFront += __popcll(wballot(v == PS_FRONT || v == PS_RESUME));
+      nNew += __popcll(wballot(v == PS_BLAS));
+      nPin += __popcll(wballot(v == PS_PINNED));
+      nShade += __popcll(wballot(v == PS_SHADE));
     }
     if (++wave_iters > kWatchdogIters) { watchdog = true; break; }   // an exit every wave reaches, whatever the data
     const int busy = nFront + nNew + nPin + nShade;
@@ -1175,7 +1170,7 @@ __global__ __launch_bounds__(64) void k_pool(DevScene S, FrameParams P, float4* 
       ph_trips[4]++; ph_lanes[4] += (unsigned long long)min(total, 64);
 #endif
       int x = 0, y = 0;
-      if (wave_fetch_pixels(P, __ballot(mine >= 0), mine >= 0, next, ntiles, wc, exhausted, x, y)) {
+      if (wave_fetch_pixels(P, wballot(mine >= 0), mine >= 0, next, ntiles, wc, exhausted, x, y)) {
         float seed = P.seed;
         v3 o, d;
         camera_ray<kPOffAfterScene>(P, x, y, seed, o, d);
@@ -1233,7 +1228,7 @@ __global__ __launch_bounds__(64) void k_pool(DevScene S, FrameParams P, float4* 
       unsigned long long steps = 0;
       const unsigned long long step_cap = (unsigned long long)P.watchdog_steps * 64ull;   // between two re-feeds
       for (;;) {
-        unsigned long long mA = __ballot(mys >= 0);
+        unsigned long long mA = wballot(mys >= 0);
         int nA = __popcll(mA);
         if (taken < total && (first || 64 - nA >= P.pool_inloop || nA < exit_below)) {     // feed the idle lanes
           int r = __popcll(~mA & below);
@@ -1250,7 +1245,7 @@ __global__ __launch_bounds__(64) void k_pool(DevScene S, FrameParams P, float4* 
           R = blas_ray(o, d);
           load = false;
         }
-        mA = __ballot(mys >= 0);
+        mA = wballot(mys >= 0);
         nA = __popcll(mA);
         if (nA < exit_below) break;
         if (++steps > step_cap) { watchdog = true; break; }
@@ -1260,7 +1255,7 @@ __global__ __launch_bounds__(64) void k_pool(DevScene S, FrameParams P, float4* 
         // majority vote: this trip runs EITHER the interior-node step OR the leaf step (see mode 3)
         bool active = mys >= 0;
         bool interior = active && cur >= 0;
-        int nI = __popcll(__ballot(interior));
+        int nI = __popcll(wballot(interior));
         if (nI >= nA - nI) {
           if (interior) cur = blas_node_step<COUNT>(S, cur, R, best.t, bl, sp, lc);
         } else if (active && !interior) {
@@ -1343,7 +1338,7 @@ __global__ __launch_bounds__(64) void k_pool(DevScene S, FrameParams P, float4* 
 // ---------------------------------------------------------------------------------------------------
 // Append the alive lanes of this wave to a queue: ballot, prefix popcount, one atomic per wave.
 __device__ __forceinline__ int wave_append(bool alive, unsigned int* counter) {
-  unsigned long long m = __ballot(alive);
+  unsigned long long m = wballot(alive);
   if (m == 0) return -1;
   int lane = threadIdx.x & 63;
   int leader = __ffsll((long long)m) - 1;

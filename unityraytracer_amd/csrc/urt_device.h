@@ -22,8 +22,10 @@ struct DevScene {
   const float4* sphere_tlas; int n_sphere_tlas;
   // spheres (RS:51-55): position.xyz + radius; materials as 3 x float4
   const float4* sphere_pr;   int n_spheres;
-  // materials (RS:29-34) of the spheres [0, n_spheres) then of the mesh objects, 3 x float4 each:
-  //   [3i] albedo.xyz, smoothness  [3i+1] specular.xyz, 0  [3i+2] emission.xyz, 0
+  // materials: spheres [0, n_spheres), then the mesh objects, then the ground plane (RS:164-170); 4 x float4 each, holding what
+  // Shade derives from the material alone, precomputed on the host (context.cpp pack_material):
+  //   [4i] (1/diffChance) * albedo', specChance   [4i+1] (1/specChance) * specular, specChance + diffChance
+  //   [4i+2] emission, diffChance                  [4i+3] alpha, 1/(alpha+1), (alpha+2)/(alpha+1), 0
   const float4* materials;
   // mesh objects (RS:43-49)
   const int32_t* mesh_root;  int n_meshes;
