@@ -7,6 +7,7 @@ lib = _lib.load()
 lib.urt_debug_read_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 import itertools
 cfg = sys.argv[1] if len(sys.argv) > 1 else None
+frames = int(sys.argv[2]) if len(sys.argv) > 2 else 16          # frames of the ONE launch the stamps describe (frame batching)
 for (w, h, b), wpc in itertools.product(((1920, 1080, 8),), (20,)):
     sc = scenes.CONFIGS[cfg]() if cfg else scenes.config3(w, h)
     if not cfg: sc.num_bounces = b
@@ -18,7 +19,8 @@ for (w, h, b), wpc in itertools.product(((1920, 1080, 8),), (20,)):
     for _ in range(3): m.OnRenderImage()
     ctx.synchronize()
     junk = np.zeros((nw, 32), np.uint64); lib.urt_debug_read_stamps(ctx._h, junk.ctypes.data_as(C.c_void_p), nw * 32)   # clears
-    m.OnRenderImage(); ctx.synchronize()
+    for _ in range(frames): m.OnRenderImage()
+    ctx.synchronize()
     st = np.zeros((nw, 32), np.uint64)
     lib.urt_debug_read_stamps(ctx._h, st.ctypes.data_as(C.c_void_p), nw * 32)
     t = st[:, 0:4].astype(np.float64) / 100.0; lanes = st[:, 4:8].astype(np.float64); trips = st[:, 8:12].astype(np.float64)
@@ -32,7 +34,7 @@ for (w, h, b), wpc in itertools.product(((1920, 1080, 8),), (20,)):
     print(f"   waves {ok.sum()}: start p50 {np.median(start):.0f} max {start.max():.0f} us; work ran dry (per wave) p10 {np.percentile(dry, 10):.0f} p50 {np.median(dry):.0f} max {dry.max():.0f} us; "
           f"end p10 {np.percentile(end, 10):.0f} p50 {np.median(end):.0f} p90 {np.percentile(end, 90):.0f} p99 {np.percentile(end, 99):.0f} max {end.max():.0f} us")
     names = ["FRONT", "BLAS", "SHADE"]
-    print(f"{w}x{h} b={b}: wave lifetime mean {life.mean():.0f} us, end p50 {np.median(end):.0f} p90 {np.percentile(end, 90):.0f} max {end.max():.0f} us")
+    print(f"{w}x{h} b={b}, {frames} frames in the launch: wave lifetime mean {life.mean():.0f} us, end p50 {np.median(end):.0f} p90 {np.percentile(end, 90):.0f} max {end.max():.0f} us")
     for q in range(3):
         print(f"   {names[q]:5s}: {t[:, q].sum() / life.sum() * 100:5.1f} % of wave time, {trips[:, q].mean():7.1f} trips/wave, {lanes[:, q].sum() / max(1, trips[:, q].sum()):5.1f} lanes/trip, {t[:, q].sum() / max(1, trips[:, q].sum()):7.2f} us/trip")
     print(f"   BLAS inner: {trips[:, 3].mean():8.1f} steps/wave, {lanes[:, 3].sum() / max(1, trips[:, 3].sum()):5.1f} active lanes/step, {t[:, 1].sum() / max(1, trips[:, 3].sum()) * 1000:7.1f} ns/step")

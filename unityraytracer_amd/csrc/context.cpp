@@ -103,7 +103,7 @@ struct urt_context {
   float trace_ms = 0;
 
   int opt_count_stats = 0, opt_time_dispatch = 0, opt_kernel_mode = 3;
-  int opt_block_threads = 64, opt_xcd_run = 1, opt_refill_min = 16, opt_waves_per_cu = 0 /* auto */, opt_blas_min = 28, opt_blas_exit = 14;
+  int opt_block_threads = 64, opt_xcd_run = 1, opt_refill_min = 16, opt_waves_per_cu = 0 /* auto */, opt_blas_min = 28, opt_blas_exit = 0 /* auto */;
   int opt_pool_k = 2, opt_pool_refill = 32, opt_pool_blas_min = 48, opt_pool_blas_exit = 8, opt_pool_inloop = 16, opt_pool_other_min = 24;   // kernel_mode 4
   int opt_sched_block = 0;                  // kernel_mode 3: threads per workgroup (64 or 256; 0 = 256 when there is a BVH top to share)
   int opt_stack_pad = 0;                    // test hook: extra (unused) entries per traversal stack, to reach the > 64 KiB LDS launch path
@@ -608,7 +608,10 @@ int do_dispatch(urt_context* ctx, int kernel, int gx, int gy, int gz, int first_
   P.first_group_row = first_row; P.row_stride = row_stride;
   P.n_strips = first_row < group_rows ? (group_rows - first_row + row_stride - 1) / row_stride : 0;
   P.tlas_stack = ctx->tlas_stack; P.blas_stack = ctx->blas_stack + ctx->opt_stack_pad; P.watchdog_steps = ctx->watchdog_steps;
-  P.block_threads = ctx->opt_block_threads; P.xcd_run = ctx->opt_xcd_run; P.tile_order = ctx->opt_tile_order; P.refill_min = ctx->opt_refill_min; P.blas_min = ctx->opt_blas_min; P.blas_exit = ctx->opt_blas_exit; P.shade_min = ctx->opt_shade_min; P.sky_min = ctx->opt_sky_min;
+  P.block_threads = ctx->opt_block_threads; P.xcd_run = ctx->opt_xcd_run; P.tile_order = ctx->opt_tile_order; P.refill_min = ctx->opt_refill_min; P.blas_min = ctx->opt_blas_min;
+  // the traversal phase yields when fewer lanes than this are still traversing: measured best 14-18 with one mesh, 8-11 when rays
+  // walk several triangle BVHs per Trace() (a yielding lane then continues its object-level walk sooner)
+  P.blas_exit = ctx->opt_blas_exit > 0 ? ctx->opt_blas_exit : (S.n_meshes > 1 ? 9 : 14); P.shade_min = ctx->opt_shade_min; P.sky_min = ctx->opt_sky_min;
   P.n_frames = 1; P.frame_stride = 0;
   if (P.n_strips == 0 || P.tiles_x == 0) return URT_OK;
   if ((uint64_t)P.tiles_x * (uint64_t)P.n_strips * 64u * (uint64_t)kMaxFramesPerLaunch >= 0xffffffffull)
@@ -1139,7 +1142,7 @@ int urt_set_option(urt_context* ctx, const char* name, int value) {
     if (value < 1 || value > 64) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "blas_min must be in [1, 64]");
     ctx->opt_blas_min = value;
   } else if (std::strcmp(name, "blas_exit") == 0) {
-    if (value < 1 || value > 64) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "blas_exit must be in [1, 64]");
+    if (value < 0 || value > 64) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "blas_exit must be in [0, 64] (0 = auto)");
     ctx->opt_blas_exit = value;
   } else if (std::strcmp(name, "refill_min") == 0) {
     if (value < 1 || value > 64) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "refill_min must be in [1, 64]");
