@@ -136,7 +136,7 @@ def main():
     overlap = world > 1 and os.environ.get("URT_BENCH_NO_OVERLAP") != "1"
     burst = 1
     if world > 1:
-        burst = max(1, min(16, args.frames_per_launch if args.frames_per_launch else int(os.environ.get("URT_BENCH_BURST", "8"))))
+        burst = max(1, min(16, args.frames_per_launch if args.frames_per_launch else int(os.environ.get("URT_BENCH_BURST", "16"))))
         ctx.set_option("frames_per_launch", burst)
         n_floats = strips.packed_rows(height, world) * width * 4
         ring = 2 * burst

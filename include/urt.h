@@ -159,7 +159,7 @@ typedef struct urt_counters {
 /* Options: "blas_builder" (0 = binned-SAH triangle BVH built on host threads, the default: best trees; 1 = LBVH built on the GPU
  *                          from the uploaded buffers — Morton sort + Karras hierarchy, csrc/lbvh.hip: milliseconds instead of tens
  *                          of milliseconds for scenes whose objects move; same pixels),
- *          "frames_per_launch" (0 = auto: own stream -> up to 16 frames / ~32 M pixels per launch, caller's stream -> 1;
+ *          "frames_per_launch" (0 = auto: own stream -> 16 frames per launch (fewer if 16 Result slots exceed 8 GiB), caller's stream -> 1;
  *                               1 = every dispatch is its own launch; 2..16 = batch that many, also on a caller's stream),
  *          "count_stats" (0/1: per-dispatch traversal counters, slower build of the kernel),
  *          "time_dispatch" (0/1: bracket each dispatch with HIP events, read by urt_get_counters),

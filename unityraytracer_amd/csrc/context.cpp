@@ -126,7 +126,7 @@ struct urt_context {
   float last_prepare_ms = 0;                // host wall time of the last scene preparation (buffers -> device scene)
   int n_scene_tris = 0;                     // triangles of the prepared scene
   int scene_max_depth = 0;
-  int opt_frames_per_launch = 0;            // 0 = auto (own stream: up to 16 frames / ~32 M pixels per launch; caller's stream: 1), 1 = off, 2..16
+  int opt_frames_per_launch = 0;            // 0 = auto (own stream: 16 frames per launch, fewer when 16 Result slots would exceed 8 GiB; caller's stream: 1), 1 = off, 2..16
   uint64_t scene_epoch = 0;                 // bumps at every scene preparation
   struct PostOp { int kind; int frame; urt_handle tex; urt_handle dst; float sample; int first_row, row_stride; void* dense; };   // kind 0 = blit_add(tex@frame -> dst), 1 = pack_rows(tex -> dense)
   struct Pending {
@@ -561,8 +561,10 @@ int batch_limit(urt_context* ctx, const FrameParams& P) {
   int lim = ctx->opt_frames_per_launch;
   if (lim == 0) {
     if (ctx->stream != ctx->own_stream) return 1;        // a caller that shares its stream expects the work ON the stream when dispatch returns
-    uint64_t px = (uint64_t)P.tiles_x * 64u * (uint64_t)P.n_strips;
-    lim = (int)std::min<uint64_t>(kMaxFramesPerLaunch, std::max<uint64_t>(1, (32u * 1024u * 1024u + px - 1) / std::max<uint64_t>(1, px)));   // 1080p: 16, 2160p: 4
+    // as many frames as the kernel-argument table holds (16), within 8 GiB of Result slots: 2160p still gains 3-8 % from 16
+    // frames per launch over 5 (gpurun_out/r2_fpl4k.log), and 16 x 133 MB is nothing on a 288 GB part
+    uint64_t frame_bytes = (uint64_t)P.width * (uint64_t)P.height * sizeof(float4);
+    lim = (int)std::min<uint64_t>(kMaxFramesPerLaunch, std::max<uint64_t>(1, (8ull << 30) / std::max<uint64_t>(1, frame_bytes)));
   }
   return std::max(1, std::min(lim, (int)kMaxFramesPerLaunch));
 }
