@@ -562,7 +562,7 @@ int batch_limit(urt_context* ctx, const FrameParams& P) {
   if (lim == 0) {
     if (ctx->stream != ctx->own_stream) return 1;        // a caller that shares its stream expects the work ON the stream when dispatch returns
     // as many frames as the kernel-argument table holds (16), within 8 GiB of Result slots: 2160p still gains 3-8 % from 16
-    // frames per launch over 5 (gpurun_out/r2_fpl4k.log), and 16 x 133 MB is nothing on a 288 GB part
+    // frames per launch over 5 (profiles/r02_logs/r2_fpl4k.log), and 16 x 133 MB is nothing on a 288 GB part
     uint64_t frame_bytes = (uint64_t)P.width * (uint64_t)P.height * sizeof(float4);
     lim = (int)std::min<uint64_t>(kMaxFramesPerLaunch, std::max<uint64_t>(1, (8ull << 30) / std::max<uint64_t>(1, frame_bytes)));
   }
