@@ -64,6 +64,7 @@ URT_API int urt_synchronize(urt_context* ctx);
  * frame is too small to fill 256 CUs through its 8-bounce tail; "frames_per_launch" below).  Every call that could observe
  * an image (readback, synchronize, counters, Blit to another image, SetPixels, release, option changes, ...) submits the
  * deferred work first, so results and ordering are exactly those of immediate execution (RM:806-820 is in-order).
+ * An error of deferred work (a failing launch) is reported by the call that submits it.
  * urt_flush submits the deferred work to the stream without waiting — for callers that synchronise by their own means
  * (their own stream + events); with a caller-owned stream deferral is off unless "frames_per_launch" is set explicitly. */
 URT_API int urt_flush(urt_context* ctx);
@@ -249,6 +250,10 @@ URT_API const char* urt_host_last_error(void);
 /* Radiance RGBE (.hdr, FORMAT=32-bit_rle_rgbe, flat or new-style RLE scanlines) -> RGBA32F, row 0 = bottom: the pixels a
  * caller hands to urt_texture_set_pixels for "_SkyboxTexture" (RM:776).  out_rgba == NULL queries the size. */
 URT_API int urt_host_load_hdr(const char* path, int* out_width, int* out_height, float* out_rgba, size_t capacity_floats);
+/* RGBA32F image -> RGBA32F image of another size with a separable Mitchell-Netravali filter: the importer step the reference's sky
+ * assets go through (`maxTextureSize: 2048`, `resizeAlgorithm: 0`, Assets/Skyboxes/CloudedSunGlow4k.hdr.meta:36,73).  An approximation
+ * of Unity's closed-source resampler (its BC6H compression is not reproduced). */
+URT_API int urt_host_resize_rgba(const float* src, int width, int height, float* dst, int new_width, int new_height);
 /* RGBA32F image (row 0 = bottom) -> .pfm (float RGB, bottom row first). */
 URT_API int urt_host_write_pfm(const char* path, const float* rgba, int width, int height);
 /* RGBA32F linear image -> 8-bit sRGB .png (what ScreenCapture.CaptureScreenshot produces for RM:762). */

@@ -1,25 +1,34 @@
-# time from SetData to the first frame when ONE MeshObject of a big scene moves (per-MeshObject BVH cache)
+# Scene-preparation time (SetData -> ready device scene, host wall clock reported by the library) for the reference's dynamic-scene
+# protocol (RM:215-230: any move re-uploads EVERY buffer): nothing moved / one MeshObject moved / all moved, with the host SAH builder
+# (per-MeshObject BVH cache) and with the GPU LBVH builder.   python scripts/dynamic_scene.py [C4 C5]
 import sys, time
 sys.path.insert(0, '.')
 import numpy as np
 from unityraytracer_amd import Context, RayTraceMaster, scenes
 ctx = Context(0)
 for name in (sys.argv[1:] or ["C4", "C5"]):
-    sc = scenes.CONFIGS[name]()
-    m = RayTraceMaster(ctx, sc)
-    t = time.perf_counter(); m.OnRenderImage(); ctx.synchronize(); t_first = time.perf_counter() - t
-    t = time.perf_counter(); m.OnRenderImage(); ctx.synchronize(); t_steady = time.perf_counter() - t
-    mo = sc.mesh_objects.copy()
-    k = len(mo) - 1
-    mat = np.asarray(mo[k]["localToWorldMatrix"], np.float32).copy(); mat[12] += 0.1; mo[k]["localToWorldMatrix"] = mat
-    lo, hi = scenes.mesh_bounds(mo, sc.vertices, sc.indices)
-    bvh = scenes.build_object_bvh(lo, hi)
-    r0, b0 = ctx.blas_cache_stats()
-    t = time.perf_counter()
-    for buf, data in ((m._meshObjectBuffer, mo), (m._vertexBuffer, sc.vertices), (m._indexBuffer, sc.indices), (m._normalBuffer, sc.normals), (m._meshObjectBVHBuffer, bvh)):
-        buf.SetData(data)
-    m.OnRenderImage(); ctx.synchronize(); t_moved = time.perf_counter() - t
-    r1, b1 = ctx.blas_cache_stats()
-    print(f"{name}: first frame (all {len(mo)} MeshObjects built) {t_first*1e3:.1f} ms; steady frame {t_steady*1e3:.2f} ms; "
-          f"frame after moving one MeshObject and re-uploading every buffer {t_moved*1e3:.1f} ms ({b1-b0} built, {r1-r0} reused)", flush=True)
-    m.OnDisable()
+    sc = scenes.CONFIGS[name](640, 360)
+    for builder in (0, 1):
+        ctx.set_option("blas_builder", builder)
+        m = RayTraceMaster(ctx, sc)
+        m.OnRenderImage(); first = ctx.scene_info()["prepare_ms"]
+        def reupload(mo):
+            lo, hi = scenes.mesh_bounds(mo, sc.vertices, sc.indices)
+            bvh = scenes.build_object_bvh(lo, hi)
+            for buf, data in ((m._meshObjectBuffer, mo), (m._vertexBuffer, sc.vertices), (m._indexBuffer, sc.indices), (m._normalBuffer, sc.normals), (m._meshObjectBVHBuffer, bvh)):
+                buf.SetData(data)
+            return ctx.scene_info()["prepare_ms"]
+        same = min(reupload(sc.mesh_objects) for _ in range(3))
+        one = sc.mesh_objects.copy()
+        mat = np.asarray(one[-1]["localToWorldMatrix"], np.float32).copy(); mat[12] += 0.1; one[-1]["localToWorldMatrix"] = mat
+        r0, b0 = ctx.blas_cache_stats()
+        t_one = reupload(one)
+        r1, b1 = ctx.blas_cache_stats()
+        allm = sc.mesh_objects.copy()
+        for k in range(len(allm)):
+            mat = np.asarray(allm[k]["localToWorldMatrix"], np.float32).copy(); mat[12] += 0.05 * (k + 1); allm[k]["localToWorldMatrix"] = mat
+        t_all = reupload(allm)
+        print(f"{name} {sc.n_triangles} triangles, {len(sc.mesh_objects)} MeshObjects, builder {'GPU LBVH' if builder else 'host SAH'}: first {first:.1f} ms; "
+              f"re-upload unchanged {same:.1f} ms; one moved {t_one:.1f} ms" + (f" ({b1 - b0} built, {r1 - r0} reused)" if not builder else "") + f"; all moved {t_all:.1f} ms", flush=True)
+        m.OnDisable()
+ctx.set_option("blas_builder", 0)

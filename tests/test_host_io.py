@@ -133,3 +133,28 @@ def test_write_png_is_a_valid_srgb_png(built_library, tmp_path):
     assert np.abs(px[2, :, 0].astype(int) - np.round(srgb * 255).astype(int)).max() <= 1
     from PIL import Image                                       # and an independent decoder agrees
     assert np.array_equal(np.asarray(Image.open(p)), px)
+
+
+def test_mitchell_resize_and_sky_import_limit(built_library, tmp_path):
+    """urt_host_resize_rgba: constant images stay constant (normalised weights), a linear ramp stays linear away from the edges,
+    energy is preserved on a 2:1 downscale; load_sky applies the importer's maxTextureSize (Assets/Skyboxes/*.hdr.meta:36)."""
+    const = np.full((12, 20, 4), 0.75, np.float32)
+    assert np.allclose(host_io.resize(const, 7, 5), 0.75, atol=1e-6)
+    ramp = np.zeros((8, 64, 4), np.float32)
+    ramp[..., 0] = np.arange(64, dtype=np.float32)[None, :]
+    small = host_io.resize(ramp, 32, 8)
+    want = (np.arange(32) * 2 + 0.5).astype(np.float32)                       # centres of the 2-texel cells
+    assert np.allclose(small[4, 4:-4, 0], want[4:-4], atol=1e-3)
+    rng = np.random.default_rng(3)
+    img = rng.uniform(0, 4, (64, 128, 4)).astype(np.float32)
+    half = host_io.resize(img, 64, 32)
+    assert abs(float(half.mean()) - float(img.mean())) < 0.02
+    # a 96x48 "sky" with the limit set to 32: 32x16 comes back, row 0 still the bottom row
+    yy = np.linspace(0.1, 3.0, 48, dtype=np.float32)[::-1, None]                # file rows are top first: brightest at the top of the FILE
+    rgb = np.repeat(np.repeat(yy[:, :, None], 96, axis=1), 3, axis=2)
+    path = str(tmp_path / "big.hdr")
+    write_hdr(path, float_to_rgbe(rgb.astype(np.float64)), rle=False)
+    sky = host_io.load_sky(path, max_texture_size=32)
+    assert sky.shape == (16, 32, 4)
+    assert sky[0, 5, 0] < sky[-1, 5, 0]                                        # bottom row (file's last) is the dim one
+    assert host_io.load_sky(path, max_texture_size=4096).shape == (48, 96, 4)  # under the limit: untouched

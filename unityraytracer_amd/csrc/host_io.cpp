@@ -6,6 +6,7 @@
 //   urt_host_write_pfm    RGBA32F image -> .pfm (float RGB, bottom row first: the same row order as Result)
 //   urt_host_write_png    RGBA32F linear image -> 8-bit sRGB .png, the kind of file RM:762's ScreenCapture.CaptureScreenshot
 //                         writes ("Screenshots/<Time.time>-<_currentSample>.png"); stored (uncompressed) deflate blocks
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -65,6 +66,52 @@ inline unsigned char srgb8(float x) {           // linear -> sRGB transfer, clam
 }  // namespace
 
 extern "C" {
+
+// Downscale to the importer's `maxTextureSize` (Assets/Skyboxes/*.hdr.meta:36 = 2048) with the resize filter the .meta names
+// (platformSettings.resizeAlgorithm: 0 = Mitchell): separable Mitchell-Netravali (B = C = 1/3), the kernel widened by the scale
+// factor (area filtering), edges clamped, weights normalised.  Unity's own resampler is closed source — its edge rule and the
+// BC6H compression the .meta also asks for (textureCompression: 1) are NOT reproduced: an approximation of the import, unpinned.
+static inline float mitchell(float x) {
+  x = std::fabs(x);
+  const float B = 1.0f / 3.0f, C = 1.0f / 3.0f;
+  if (x < 1.0f) return ((12 - 9 * B - 6 * C) * x * x * x + (-18 + 12 * B + 6 * C) * x * x + (6 - 2 * B)) / 6.0f;
+  if (x < 2.0f) return ((-B - 6 * C) * x * x * x + (6 * B + 30 * C) * x * x + (-12 * B - 48 * C) * x + (8 * B + 24 * C)) / 6.0f;
+  return 0.0f;
+}
+
+static void resize_axis(const float* src, int n_src, int other, int n_dst, float* dst, bool along_x) {
+  // along_x: src is [other rows][n_src cols][4], dst [other][n_dst][4]; else src is [n_src rows][other cols][4], dst [n_dst][other][4]
+  float scale = (float)n_src / (float)n_dst, support = 2.0f * std::max(1.0f, scale), inv = 1.0f / std::max(1.0f, scale);
+  std::vector<float> w;
+  for (int d = 0; d < n_dst; d++) {
+    float centre = ((float)d + 0.5f) * scale - 0.5f;
+    int lo = (int)std::floor(centre - support), hi = (int)std::ceil(centre + support);
+    w.assign((size_t)(hi - lo + 1), 0.0f);
+    float sum = 0;
+    for (int k = lo; k <= hi; k++) { float v = mitchell(((float)k - centre) * inv); w[(size_t)(k - lo)] = v; sum += v; }
+    for (int o = 0; o < other; o++) {
+      float acc[4] = {0, 0, 0, 0};
+      for (int k = lo; k <= hi; k++) {
+        int kk = std::min(std::max(k, 0), n_src - 1);
+        const float* p = along_x ? src + 4 * ((size_t)o * n_src + kk) : src + 4 * ((size_t)kk * other + o);
+        float wk = w[(size_t)(k - lo)] / sum;
+        for (int c = 0; c < 4; c++) acc[c] += wk * p[c];
+      }
+      float* q = along_x ? dst + 4 * ((size_t)o * n_dst + d) : dst + 4 * ((size_t)d * other + o);
+      for (int c = 0; c < 4; c++) q[c] = acc[c];
+    }
+  }
+}
+
+int urt_host_resize_rgba(const float* src, int width, int height, float* dst, int new_width, int new_height) {
+  if (!src || !dst || width <= 0 || height <= 0 || new_width <= 0 || new_height <= 0) return io_fail(URT_ERR_INVALID_ARGUMENT, "resize: bad arguments");
+  try {
+    std::vector<float> tmp((size_t)new_width * height * 4);
+    resize_axis(src, width, height, new_width, tmp.data(), true);
+    resize_axis(tmp.data(), height, new_width, new_height, dst, false);
+    return URT_OK;
+  } catch (...) { return io_fail(URT_ERR_OUT_OF_MEMORY, "resize: allocation failed"); }
+}
 
 const char* urt_host_io_last_error(void) { return g_io_error.c_str(); }
 

@@ -36,3 +36,24 @@ def write_png(path: str, rgba: np.ndarray):
     lib = _lib.load()
     a = np.ascontiguousarray(rgba, dtype=np.float32)
     _check(lib, lib.urt_host_write_png(path.encode(), a.ctypes.data_as(C.c_void_p), a.shape[1], a.shape[0]))
+
+
+def resize(rgba: np.ndarray, new_width: int, new_height: int) -> np.ndarray:
+    """Separable Mitchell-Netravali resize of an (H, W, 4) float32 image (include/urt.h urt_host_resize_rgba)."""
+    lib = _lib.load()
+    a = np.ascontiguousarray(rgba, dtype=np.float32)
+    out = np.zeros((new_height, new_width, 4), dtype=np.float32)
+    _check(lib, lib.urt_host_resize_rgba(a.ctypes.data_as(C.c_void_p), a.shape[1], a.shape[0], out.ctypes.data_as(C.c_void_p), new_width, new_height))
+    return out
+
+
+def load_sky(path: str, max_texture_size: int = 2048) -> np.ndarray:
+    """A .hdr sky as the reference's importer settings would deliver it to `_SkyboxTexture` (RM:776): loaded, then downscaled so
+    that neither side exceeds `maxTextureSize` (Assets/Skyboxes/*.hdr.meta:36), aspect kept.  (BC6H compression not reproduced.)"""
+    img = load_hdr(path)
+    h, w = img.shape[:2]
+    big = max(w, h)
+    if big <= max_texture_size:
+        return img
+    s = max_texture_size / big
+    return resize(img, max(1, int(round(w * s))), max(1, int(round(h * s))))
