@@ -263,7 +263,9 @@ def main():
                     traffic_source = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command, not this run)"
             except Exception:
                 traffic = None
-        kname = "k_sched<false,256,false,false>" if scene.num_rays == 1 else "k_sched<false,256,false,true>"
+        # k_sched<COUNT, BLOCK, FMODE, MULTI>: FMODE 0 one mesh, 2 listed FRONT (2..12 MeshObjects), 1 more than that (kernels.hip)
+        n_mo = len(scene.mesh_objects)
+        kname = f"k_sched<false, 256, {0 if n_mo <= 1 else 2 if n_mo <= 12 else 1}, {'true' if scene.num_rays > 1 else 'false'}>"
         roofline = {"bound": "hbm", "kernel": f"trace: {kname} (kernel_mode 3, the default)" if args.kernel_mode in (None, 3) else f"trace kernel of kernel_mode {args.kernel_mode}",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "traffic": traffic, "traffic_source": traffic_source,

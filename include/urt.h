@@ -173,7 +173,8 @@ typedef struct urt_counters {
  *          mode 3: "blas_min" / "blas_exit" / "shade_min" / "sky_min" (1..64: vote thresholds), "shade_split" (-1 auto | 0 | 1: surface hits and
  *                  sky misses as separate phases), "sched_block" (0 auto | 64 | 256),
  *                  "top_nodes" (0..256 triangle-BVH nodes kept in LDS), "top_front" (-1 auto | 0 | 1: where that top is
- *                  walked), "lds_tlas" (0/1: small object-level tables in LDS),
+ *                  walked), "front_list" (-1 auto | 0 | 1: scenes of <= 12 MeshObjects collect the objects a ray must test in a list
+ *                  and work the lists off in voted trips), "lds_tlas" (0/1: small object-level tables in LDS),
  *          mode 4: "pool_k" (1..4), "pool_refill", "pool_blas_min" (1..256), "pool_blas_exit", "pool_inloop",
  *                  "pool_other_min" (1..64),
  *          "blas_leaf_max" (1..8: triangles per BVH leaf; rebuilds the BVH),

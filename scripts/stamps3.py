@@ -13,6 +13,8 @@ for (w, h, b), wpc in itertools.product(((1920, 1080, 8),), (20,)):
     if not cfg: sc.num_bounces = b
     w, h, b = sc.width, sc.height, sc.num_bounces
     ctx.set_option("kernel_mode", 3); ctx.set_option("waves_per_cu", wpc)
+    for kv in sys.argv[3:]:                                        # extra options: name=value ...
+        k, v = kv.split("="); ctx.set_option(k, int(v))
     print(f"--- waves/CU {wpc}")
     m = RayTraceMaster(ctx, sc)
     nw = 8192

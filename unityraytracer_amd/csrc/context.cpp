@@ -108,6 +108,7 @@ struct urt_context {
   int opt_sched_block = 0;                  // kernel_mode 3: threads per workgroup (64 or 256; 0 = 256 when there is a BVH top to share)
   int opt_stack_pad = 0;                    // test hook: extra (unused) entries per traversal stack, to reach the > 64 KiB LDS launch path
   int opt_shade_min = 32, opt_sky_min = 32; // kernel_mode 3
+  int opt_front_list = -1;                  // kernel_mode 3: listed FRONT for scenes of <= 12 MeshObjects (-1 auto = on, 0 off)
   int opt_shade_split = -1;                 // kernel_mode 3: -1 = auto (= split: measured better or equal on C2-C5), 0 = surface hits and misses shaded in one trip
   int opt_tile_order = 0;                   // persistent modes: order in which the frame's tiles are handed out
   int opt_lds_tlas = 1;                     // kernel_mode 3: object-level heaps, roots and spheres in LDS when small
@@ -136,7 +137,7 @@ struct urt_context {
     DevScene S{};
     FrameParams P{};                        // frame 0's; the frames agree on everything but the table entries
     FrameTable T{};
-    bool top_in_front = false, count = false;
+    int front_mode = 0; bool count = false;
     std::vector<PostOp> ops;
   } pend;
   float4* slab = nullptr;                   // slab_frames x slab_stride float4: Result slots of the batched frames
@@ -464,8 +465,9 @@ int ensure_slab(urt_context* ctx, urt_handle h, Texture& t, int frames) {
   return URT_OK;
 }
 
-// kernel_mode 3: what lives in the workgroup's LDS next to the stacks (fills P.top_nodes, P.lds_*, P.block_threads)
-void configure_sched(urt_context* ctx, const DevScene& S, FrameParams& P) {
+// kernel_mode 3: what lives in the workgroup's LDS next to the stacks (fills P.top_nodes, P.lds_*, P.block_threads, P.list_base,
+// P.tlas_stack) and how FRONT treats MeshObjects (returns the front mode of kernels.h launch_sched)
+int configure_sched(urt_context* ctx, const DevScene& S, FrameParams& P, bool top_in_front) {
   // independent waves; the waves of a workgroup share one LDS copy of the top of the triangle-BVH forest, which shrinks
   // until 5 waves/SIMD (what 96 VGPRs allow) fit the 160 KiB of a CU next to their traversal stacks
   int t = std::min(std::min(ctx->opt_top_nodes, (int)kTopOrderNodes), ctx->n_blas_nodes);
@@ -480,11 +482,15 @@ void configure_sched(urt_context* ctx, const DevScene& S, FrameParams& P) {
   const size_t budget = 156 * 1024;                          // (a little of the 160 KiB goes to allocation granules)
   while (P.top_nodes > 0 && sched_lds_bytes(S, P) * groups > budget) P.top_nodes /= 2;
   if (sched_lds_bytes(S, P) * groups > budget) { P.lds_mesh = 0; P.lds_sphere = 0; P.lds_small = 0; }
+  // listed FRONT (kernels.hip front_listed): scenes of a few MeshObjects whose heap is in LDS; the list of objects a ray has to test
+  // (<= 12 ids of 5 bits) lives in the first two entries of the lane's object-level stack, so it costs no LDS
+  bool listed = top_in_front && P.top_nodes > 0 && P.lds_mesh && S.n_meshes <= 12 && ctx->opt_front_list != 0;
+  return listed ? 2 : (top_in_front && P.top_nodes > 0) ? 1 : 0;
 }
 
 // Launch the phase-scheduled trace kernel for P.n_frames frames (uniforms T) into result + f * P.frame_stride.
 int launch_sched_frames(urt_context* ctx, const DevScene& S, const FrameParams& P, const FrameTable& T, float4* result,
-                        bool top_in_front, bool count) {
+                        int front_mode, bool count) {
   int waves_per_block = P.block_threads / 64;
   long want = ((long)P.tiles_x * P.n_strips * P.n_frames + waves_per_block - 1) / waves_per_block;
   // resident waves per CU: every slot the registers allow (k_sched: 96 VGPRs -> 5 waves/SIMD = 20 per CU).  While the
@@ -500,7 +506,7 @@ int launch_sched_frames(urt_context* ctx, const DevScene& S, const FrameParams& 
     rc = take_event(ctx, &e1); if (rc) return rc;
     URT_HIP(ctx, hipEventRecord(e0, ctx->stream));
   }
-  hipError_t le = launch_sched(S, P, T, result, ctx->d_counters, ctx->d_next, nb, top_in_front, count, ctx->stream);
+  hipError_t le = launch_sched(S, P, T, result, ctx->d_counters, ctx->d_next, nb, front_mode, count, ctx->stream);
   if (ctx->opt_time_dispatch) {
     (void)hipEventRecord(e1, ctx->stream);
     ctx->timing.emplace_back(e0, e1);
@@ -523,7 +529,7 @@ int flush_pending(urt_context* ctx) {
   FrameParams P = B.P;
   P.n_frames = n;
   P.frame_stride = (unsigned int)ctx->slab_stride;
-  int rc = launch_sched_frames(ctx, B.S, P, B.T, ctx->slab, B.top_in_front, B.count);
+  int rc = launch_sched_frames(ctx, B.S, P, B.T, ctx->slab, B.front_mode, B.count);
   if (rc) return rc;
   size_t i = 0;
   while (i < ops.size()) {
@@ -636,8 +642,8 @@ int do_dispatch(urt_context* ctx, int kernel, int gx, int gy, int gz, int first_
   const bool full_cover = P.region_w == res->w && P.region_h == res->h && first_row == 0 && row_stride == 1;
 
   if (mode == 3) {
-    configure_sched(ctx, S, P);
     bool top_in_front = ctx->opt_top_front < 0 ? S.n_meshes > 1 : ctx->opt_top_front != 0;
+    int front_mode = configure_sched(ctx, S, P, top_in_front);
     P.shade_split = ctx->opt_shade_split != 0;
     FrameUniforms fu{};
     std::memcpy(fu.c2w, P.c2w, sizeof fu.c2w);
@@ -652,7 +658,7 @@ int do_dispatch(urt_context* ctx, int kernel, int gx, int gy, int gz, int first_
     if (B.n > 0) {
       const FrameParams& Q = B.P;
       bool same = B.tex == res_h && B.scene_epoch == ctx->scene_epoch && B.S.sky == S.sky && B.S.sky_w == S.sky_w && B.S.sky_h == S.sky_h &&
-                  B.count == count && B.top_in_front == top_in_front && Q.num_bounces == P.num_bounces && Q.num_rays == P.num_rays &&
+                  B.count == count && B.front_mode == front_mode && Q.num_bounces == P.num_bounces && Q.num_rays == P.num_rays &&
                   Q.width == P.width && Q.height == P.height && Q.region_w == P.region_w && Q.region_h == P.region_h &&
                   Q.first_group_row == P.first_group_row && Q.row_stride == P.row_stride && B.n < B.limit && limit > 1;
       if (!same) { int rc = flush_pending(ctx); if (rc) return rc; }
@@ -660,13 +666,13 @@ int do_dispatch(urt_context* ctx, int kernel, int gx, int gy, int gz, int first_
     if (limit <= 1) {                                     // not batched: trace this frame now, straight into the texture
       FrameTable T{};
       T.f[0] = fu;
-      int rc = launch_sched_frames(ctx, S, P, T, res->dev, top_in_front, count);
+      int rc = launch_sched_frames(ctx, S, P, T, res->dev, front_mode, count);
       if (rc) return rc;
     } else {
       if (B.n == 0) {
         int rc = ensure_slab(ctx, res_h, *res, limit); if (rc) return rc;
         B.limit = std::min(limit, ctx->slab_frames);
-        B.tex = res_h; B.scene_epoch = ctx->scene_epoch; B.S = S; B.P = P; B.top_in_front = top_in_front; B.count = count;
+        B.tex = res_h; B.scene_epoch = ctx->scene_epoch; B.S = S; B.P = P; B.front_mode = front_mode; B.count = count;
       }
       B.T.f[B.n] = fu;
       res->dev = ctx->slab + (size_t)B.n * ctx->slab_stride;   // Result now names this frame's slot
@@ -1161,6 +1167,9 @@ int urt_set_option(urt_context* ctx, const char* name, int value) {
   } else if (std::strcmp(name, "shade_min") == 0) {
     if (value < 1 || value > 64) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "shade_min must be in [1, 64]");
     ctx->opt_shade_min = value;
+  } else if (std::strcmp(name, "front_list") == 0) {
+    if (value < -1 || value > 1) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "front_list must be -1 (auto), 0 or 1");
+    ctx->opt_front_list = value;
   } else if (std::strcmp(name, "shade_split") == 0) {
     if (value < -1 || value > 1) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "shade_split must be -1 (auto), 0 or 1");
     ctx->opt_shade_split = value;

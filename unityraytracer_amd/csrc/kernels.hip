@@ -804,6 +804,127 @@ __device__ __forceinline__ bool trace_front(const DevScene& S, bool fresh, v3 o,
   return false;
 }
 
+// FRONT for multi-mesh scenes, "listed" form (front mode 2).  In trace_front<TOPF> the expensive bodies — the inline triangle tests
+// of single-leaf MeshObjects (wall quads: ~150 VALU) and the walk of the LDS-resident top of a big MeshObject's BVH (~60 + 50 per
+// node) — sit INSIDE the per-lane heap-walk loop: every iteration of that loop pays for both whenever any lane of the wave
+// happens to be at such a leaf.  The object-level slab test (RS:271-291) never looks at the best hit so far, so WHICH objects a ray
+// tests, and in which order, is a function of the ray and the heap alone.  Here a fresh ray first walks the whole heap (cheap:
+// ~30 VALU per node) and writes the object ids it has to test, in the reference's order (pop order, `tests` never reset: A.5),
+// as bytes into its LDS column; then the wave works the lists off in two alternating bodies: the inline triangle tests for every
+// lane whose next entry is a single-leaf MeshObject, until all lanes stand at a big one, then ONE BVH-top walk for all of
+// them.  Every lane still tests its objects in list order, so ties in t resolve exactly as before.  A lane whose ray has to enter a MeshObject's BVH below the LDS top leaves for the
+// BLAS phase and resumes with its next entry.  cs = entries left | next entry << 8.  Called by the whole wave (`mine` = lanes in
+// FRONT / RESUME); needs the object-level mesh tables in LDS and n_meshes <= 12.
+// The list: up to 12 object ids of 5 bits, six per dword, kept in two registers during the walk and then in the first two
+// entries of the lane's object-level stack column — the stack is dead once the walk is over, so the list costs no LDS at all
+// (LDS is what limits the size of the BVH top a workgroup can keep: a first version with a byte list of its own shrank that top
+// and tripled the time spent in the BLAS phase).
+__device__ __forceinline__ int list_get(const int* tl, int j) {
+  unsigned int w = (unsigned int)tl[j >= 6 ? 64 : 0];
+  return (int)((w >> (5 * (j >= 6 ? j - 6 : j))) & 31u);
+}
+
+// Returns per lane: 0 = Trace() is complete (shade next), 1 = the ray must enter a triangle BVH (BLAS phase next), 2 = not served in this
+// trip (a fresh ray whose heap walk was put off: fresh rays walk the heap together, when at least 16 of them wait or when no
+// resumed ray needs the trip — resumed rays are the majority in scenes where a ray meets several big meshes, and a walk for a
+// few fresh lanes would hold all of them up).
+template <bool COUNT>
+__device__ __forceinline__ int front_listed(const DevScene& S, const FrameParams& P, bool mine, bool fresh, v3 o, v3 d, HitRec& best, int& cs,
+                                            int* tl, int32_t& cur, LocalCounters& lc, const FrontLds& L, const float4* top, int* bl, int& sp,
+                                            unsigned int& wave_rays) {
+  int remaining = cs & 0xff, cursor = cs >> 8;
+  const int n_fresh = __popcll(wballot(mine && fresh)), n_resumed = __popcll(wballot(mine && !fresh));
+  const bool walk_now = n_fresh >= 16 || n_resumed == 0;
+  if (!walk_now) mine = mine && !fresh;
+  else wave_rays += (unsigned int)n_fresh;                  // Trace() invocations (RS:454), counted per wave
+  const bool put_off = !walk_now && fresh;
+  if (mine && fresh) {
+    best.t = URT_INF; best.kid = 0; best.u = 0; best.v = 0;
+    float t = -o.y / d.y;                                   // IntersectGroundPlane RS:156-172
+    if (t > 0 && t < best.t) { best.t = t; best.kid = 1; }
+    v3 rcp = mk3(1.0f / (d.x + kEPSILON), 1.0f / (d.y + kEPSILON), 1.0f / (d.z + kEPSILON));
+    int count = 0, check = 0;
+    unsigned int l0 = 0, l1 = 0;
+    bool seen = false;
+    if (S.n_meshes > 0) { check = 1; tl[0] = 0; }
+    while (check > 0) {                                      // IntersectMeshBVH RS:294-326, the walk alone
+      check--;
+      int bi = tl[check * 64];
+      bool hit = false; int index = -1;
+      if (bi < S.n_mesh_tlas) {
+        if (COUNT) lc.tlas_nodes++;
+        float4 a = L.mesh_tlas[2 * bi], b = L.mesh_tlas[2 * bi + 1];
+        index = as_int(a.w);
+        hit = tlas_slab(a, b, o, rcp);
+      }
+      if (hit) {
+        if (index < 0) { tl[check * 64] = bi * 2 + 1; check++; tl[check * 64] = bi * 2 + 2; check++; }
+        else seen = true;
+      }
+      if (seen && index >= 0 && index < S.n_meshes && L.mesh_root[index] != kEmptyMeshRoot) {
+        if (count < 6) l0 |= (unsigned int)index << (5 * count); else l1 |= (unsigned int)index << (5 * (count - 6));
+        count++;
+      }
+    }
+    tl[0] = (int)l0; tl[64] = (int)l1;                       // the walk's stack is dead: its first two entries keep the list
+    remaining = count; cursor = 0;
+  }
+  bool need = false;
+  bool has = mine && remaining > 0;
+  for (;;) {
+    // (1) every lane works off the single-leaf MeshObjects (<= 8 triangles: wall quads, planes) at the head of its list:
+    //     one cheap body for all of them, until every lane's next entry is a big MeshObject (or its list is done)
+    int obj = 0; int32_t root = kEmptyMeshRoot;
+    for (;;) {
+      if (has) { obj = list_get(tl, cursor); root = L.mesh_root[obj]; }
+      bool small = has && root < 0;
+      if (wballot(small) == 0) break;
+      if (small) {
+        int bi_local = -1;
+        if (L.small_tris) test_leaf<COUNT>(S, root, o, d, best, bi_local, lc, L.small_tris, L.small_first[obj]);
+        else test_leaf<COUNT>(S, root, o, d, best, bi_local, lc);
+        cursor++; remaining--; has = remaining > 0;
+      }
+    }
+    // (2) ONE walk of the LDS-resident BVH top for all the lanes that now stand at a big MeshObject: the expensive body runs with
+    //     as many lanes as the wave can muster, as often as the longest list has big entries
+    if (wballot(has) == 0) break;
+    if (has) {
+      sp = 0;
+      if (root < P.top_nodes) {
+        BlasRay R = blas_ray(o, d);
+        do root = blas_node_step_top<COUNT>(top, root, R, best.t, bl, sp, lc); while (root >= 0 && root < P.top_nodes);
+      }
+      cursor++; remaining--;
+      if (root == kBlasDone) has = remaining > 0;           // nothing of this mesh is near the ray
+      else { cur = root; need = true; has = false; }         // on to the BLAS phase; the list continues at RESUME
+    }
+  }
+  cs = remaining | (cursor << 8);
+  if (mine && !need && S.n_spheres > 0) {                    // IntersectSphereBVH RS:329-361
+    v3 rcp = mk3(1.0f / (d.x + kEPSILON), 1.0f / (d.y + kEPSILON), 1.0f / (d.z + kEPSILON));
+    int c2 = 1; tl[0] = 0; bool seen2 = false;
+    while (c2 > 0) {
+      c2--;
+      int bi = tl[c2 * 64];
+      bool hit = false; int index = -1;
+      if (bi < S.n_sphere_tlas) {
+        if (COUNT) lc.tlas_nodes++;
+        float4 a, b;
+        if (L.sphere_tlas) { a = L.sphere_tlas[2 * bi]; b = L.sphere_tlas[2 * bi + 1]; } else { a = S.sphere_tlas[2 * bi]; b = S.sphere_tlas[2 * bi + 1]; }
+        index = as_int(a.w);
+        hit = tlas_slab(a, b, o, rcp);
+      }
+      if (hit) {
+        if (index < 0) { tl[c2 * 64] = bi * 2 + 1; c2++; tl[c2 * 64] = bi * 2 + 2; c2++; }
+        else seen2 = true;
+      }
+      if (seen2 && index >= 0 && index < S.n_spheres) intersect_sphere<COUNT>(S, index, o, d, best, lc, L.sphere_pr);
+    }
+  }
+  return put_off ? 2 : need ? 1 : 0;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // mode 3: persistent waves, lanes SCHEDULED BY PHASE inside the wave.
 // Measured on mode 2 (profiles/README.md): after the first bounce only a minority of a wave's lanes needs
@@ -830,7 +951,9 @@ static constexpr unsigned int kWatchdogIters = 1u << 24;    // scheduler trips p
 // MULTI: _numRays > 1 (the running resultAverage and the ray counter are live path state only then).
 // One launch traces P.n_frames consecutive frames (frame table T): a lane whose path has ended takes its next pixel from the
 // NEXT frame once the current one is handed out, so only the last frame of a launch pays the drain of the long paths.
-template <bool COUNT, int BLOCK, bool TOPF, bool MULTI>
+// FMODE: how FRONT treats MeshObjects — 0: a ray that must enter a triangle BVH goes to the BLAS phase at once (one mesh);
+// 1: it first walks the LDS-resident top of that BVH inside FRONT (several meshes); 2: listed form of 1 (front_listed above).
+template <bool COUNT, int BLOCK, int FMODE, bool MULTI>
 __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, FrameParams P, FrameTable T, float4* __restrict__ result, DevCounters* ctr,
                                                unsigned int* __restrict__ next) {
   // LDS of the workgroup: [top of the triangle-BVH forest: top_nodes x 64 B, shared by its waves][stacks of wave 0][wave 1]...
@@ -956,12 +1079,19 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
 #endif
     if (phase == ST_FRONT) {
       // ---------------- FRONT / RESUME: Trace() up to the next triangle-BVH visit (RS:364-383) ----------------
-      wave_rays += (unsigned int)__popcll(wballot(st == ST_FRONT));     // Trace() invocations (RS:454), counted per wave
-      if (st == ST_FRONT || st == ST_RESUME) {
+      if (FMODE != 2) wave_rays += (unsigned int)__popcll(wballot(st == ST_FRONT));     // Trace() invocations (RS:454), counted per wave
+      if (FMODE == 2) {
+        bool mine = st == ST_FRONT || st == ST_RESUME;
+        int r = front_listed<COUNT>(S, P, mine, st == ST_FRONT, o, d, best, cs, tl, cur, lc, L, top, bl, sp, wave_rays);
+        if (mine && r != 2) {
+          if (r == 1) { best_i = -1; st = ST_BLAS; }
+          else st = best.t < URT_INF ? ST_SHADE : ST_SKY;
+        }
+      } else if (st == ST_FRONT || st == ST_RESUME) {
         sp = 0;
         int check = cs & 0xff; bool seen = (cs >> 8) != 0;
-        bool need = TOPF ? trace_front<COUNT, true, false>(S, st == ST_FRONT, o, d, best, check, seen, tl, 64, cur, lc, L, top, P.top_nodes, bl, &sp)
-                         : trace_front<COUNT, false, false>(S, st == ST_FRONT, o, d, best, check, seen, tl, 64, cur, lc, L);
+        bool need = FMODE == 1 ? trace_front<COUNT, true, false>(S, st == ST_FRONT, o, d, best, check, seen, tl, 64, cur, lc, L, top, P.top_nodes, bl, &sp)
+                               : trace_front<COUNT, false, false>(S, st == ST_FRONT, o, d, best, check, seen, tl, 64, cur, lc, L);
         cs = check | (seen ? 256 : 0);
         if (need) { best_i = -1; st = ST_BLAS; }
         else st = best.t < URT_INF ? ST_SHADE : ST_SKY;
@@ -1552,40 +1682,46 @@ size_t sched_lds_bytes(const DevScene& S, const FrameParams& P) {
   return f4 * 16 + (size_t)(P.tlas_stack + P.blas_stack) * 64 * (size_t)(P.block_threads / 64) * sizeof(int);
 }
 
-template <bool COUNT, int BLOCK, bool TOPF, bool MULTI>
+template <bool COUNT, int BLOCK, int FMODE, bool MULTI>
 static hipError_t launch_sched_t(const DevScene& S, const FrameParams& P, const FrameTable& T, float4* result, DevCounters* ctr,
                                  unsigned int* next, int n_blocks, size_t lds, hipStream_t st) {
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_sched<COUNT, BLOCK, TOPF, MULTI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)k_sched<COUNT, BLOCK, FMODE, MULTI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((k_sched<COUNT, BLOCK, TOPF, MULTI>), dim3(n_blocks), dim3(BLOCK), lds, st, S, P, T, result, ctr, next);
+  hipLaunchKernelGGL((k_sched<COUNT, BLOCK, FMODE, MULTI>), dim3(n_blocks), dim3(BLOCK), lds, st, S, P, T, result, ctr, next);
   return hipGetLastError();
+}
+
+template <bool COUNT, int BLOCK, int FMODE>
+static hipError_t launch_sched_m(const DevScene& S, const FrameParams& P, const FrameTable& T, float4* result, DevCounters* ctr,
+                                 unsigned int* next, int n_blocks, size_t lds, hipStream_t st) {
+  return P.num_rays > 1 ? launch_sched_t<COUNT, BLOCK, FMODE, true>(S, P, T, result, ctr, next, n_blocks, lds, st)
+                        : launch_sched_t<COUNT, BLOCK, FMODE, false>(S, P, T, result, ctr, next, n_blocks, lds, st);
 }
 
 template <bool COUNT, int BLOCK>
 static hipError_t launch_sched_b(const DevScene& S, const FrameParams& P, const FrameTable& T, float4* result, DevCounters* ctr,
-                                 unsigned int* next, int n_blocks, size_t lds, bool top_in_front, hipStream_t st) {
-  bool multi = P.num_rays > 1;
-  if (top_in_front) return multi ? launch_sched_t<COUNT, BLOCK, true, true>(S, P, T, result, ctr, next, n_blocks, lds, st)
-                                 : launch_sched_t<COUNT, BLOCK, true, false>(S, P, T, result, ctr, next, n_blocks, lds, st);
-  return multi ? launch_sched_t<COUNT, BLOCK, false, true>(S, P, T, result, ctr, next, n_blocks, lds, st)
-               : launch_sched_t<COUNT, BLOCK, false, false>(S, P, T, result, ctr, next, n_blocks, lds, st);
+                                 unsigned int* next, int n_blocks, size_t lds, int front_mode, hipStream_t st) {
+  if (front_mode == 2) return launch_sched_m<COUNT, BLOCK, 2>(S, P, T, result, ctr, next, n_blocks, lds, st);
+  if (front_mode == 1) return launch_sched_m<COUNT, BLOCK, 1>(S, P, T, result, ctr, next, n_blocks, lds, st);
+  return launch_sched_m<COUNT, BLOCK, 0>(S, P, T, result, ctr, next, n_blocks, lds, st);
 }
 
 hipError_t launch_sched(const DevScene& S, const FrameParams& P, const FrameTable& T, float4* result, DevCounters* ctr,
-                        unsigned int* next, int n_blocks, bool top_in_front, bool count, hipStream_t st) {
+                        unsigned int* next, int n_blocks, int front_mode, bool count, hipStream_t st) {
   if (n_blocks <= 0) return hipSuccess;
   if (P.block_threads != 64 && P.block_threads != 256) return hipErrorInvalidValue;   // independent waves; a workgroup shares the LDS top-of-tree copy
   if (P.n_frames < 1 || P.n_frames > kMaxFramesPerLaunch) return hipErrorInvalidValue;
+  if (front_mode == 2 && (!P.lds_mesh || S.n_meshes > 12 || P.tlas_stack < 2)) return hipErrorInvalidValue;
   hipError_t e = hipMemsetAsync(next, 0, kWorkShards * 32 * sizeof(unsigned int), st);
   if (e != hipSuccess) return e;
   size_t lds = sched_lds_bytes(S, P);
-  if (P.top_nodes <= 0) top_in_front = false;
-  if (P.block_threads == 64) return count ? launch_sched_b<true, 64>(S, P, T, result, ctr, next, n_blocks, lds, top_in_front, st)
-                                          : launch_sched_b<false, 64>(S, P, T, result, ctr, next, n_blocks, lds, top_in_front, st);
-  return count ? launch_sched_b<true, 256>(S, P, T, result, ctr, next, n_blocks, lds, top_in_front, st)
-               : launch_sched_b<false, 256>(S, P, T, result, ctr, next, n_blocks, lds, top_in_front, st);
+  if (P.top_nodes <= 0 && front_mode == 1) front_mode = 0;
+  if (P.block_threads == 64) return count ? launch_sched_b<true, 64>(S, P, T, result, ctr, next, n_blocks, lds, front_mode, st)
+                                          : launch_sched_b<false, 64>(S, P, T, result, ctr, next, n_blocks, lds, front_mode, st);
+  return count ? launch_sched_b<true, 256>(S, P, T, result, ctr, next, n_blocks, lds, front_mode, st)
+               : launch_sched_b<false, 256>(S, P, T, result, ctr, next, n_blocks, lds, front_mode, st);
 }
 
 size_t pool_lds_bytes(const FrameParams& P, int k) {

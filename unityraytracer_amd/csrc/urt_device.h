@@ -53,7 +53,7 @@ struct FrameParams {
   int first_group_row;      // multi-GPU strips: global group row of local strip 0
   int row_stride;           //                   and the stride between this rank's strips
   int n_strips;             // local strips (8 pixel rows each)
-  int tlas_stack;           // LDS entries per lane reserved for the object-level stacks
+  int tlas_stack;           // LDS entries per lane reserved for the object-level stacks (the listed FRONT keeps its object list in the first two)
   int blas_stack;           // LDS entries per lane reserved for the triangle-BVH stack
   int block_threads;        // workgroup size (64, 128 or 256)
   int tile_order;           // persistent modes: 0 = strips bottom to top (natural), 1 = top to bottom
