@@ -241,10 +241,16 @@ URT_API int urt_host_mesh_leaf_bounds(const void* mesh_objects, int n_meshes, co
 /* SetupBVHLeaves(List<Sphere>) (RM:436-455): literal != 0 keeps the inverted boxes (vmin = pos + r, vmax = pos - r). */
 URT_API int urt_host_sphere_leaf_bounds(const void* spheres, int n_spheres, int literal, urt_BVHNode* out_leaves);
 /* CreateBVH's output contract (RM:681-722): implicit heap of 2^D - 1 nodes, D = ceil(log2 n) + 1, children 2i+1 / 2i+2,
- * interior and filler nodes index -1 (fillers all-zero, RM:490-494).  The tree is a deterministic median split (the
- * reference's pairing heuristic RM:510-678 depends on .NET's unstable sort and is not reproducible). */
+ * interior and filler nodes index -1 (fillers all-zero, RM:490-494).  This one builds the tree by a deterministic median split
+ * (O(n log n)); urt_host_build_object_bvh_pairing below is the reference's own O(n^3) pairing heuristic.  Pixels do not depend on
+ * which of the two made the heap. */
 URT_API int urt_host_object_bvh_length(int n_objects);
 URT_API int urt_host_build_object_bvh(const urt_BVHNode* leaves, int n_objects, urt_BVHNode* out_nodes, int capacity);
+/* The reference's OWN builder restated literally — SetupBVHRankList / PairBVHBounds / JoinBVH / CreateBVH (RM:459-722): nearest-
+ * neighbour ranking with "forbidden" pairs last, greedy pairing from start index n-1 (the volume comparison is dead code: the
+ * candidate list is aliased, RM:670), lone trees joined under a copy of their own root, layers woven into the implicit heap.
+ * Only the order of exact ties in the ranking sort (an unstable List.Sort in the reference) is this library's choice (stable). */
+URT_API int urt_host_build_object_bvh_pairing(const urt_BVHNode* leaves, int n_objects, urt_BVHNode* out_nodes, int capacity);
 URT_API const char* urt_host_last_error(void);
 
 /* ---- host-side image I/O (no GPU needed) ---------------------------------- */

@@ -2,7 +2,8 @@
 
 f1/f2  a scene built the reference's way — RegisterObject -> RebuildObjectLists (C++ ComputeNormals RM:340-368 and the
        C++ object-level heaps RM:405-722) -> RebuildTrees -> frames — must give the same pixels on the GPU as the oracle
-       gives on those very lists, with the literal (quirky, A.7) leaf boxes as well as the tight ones;
+       gives on those very lists, with the literal (quirky, A.7) leaf boxes as well as the tight ones, and with the heap made by
+       the reference's own pairing builder (restated) as well as the median-split one;
 f3     a Radiance .hdr file on disk -> urt_host_load_hdr -> `_SkyboxTexture` (RM:776): HIP == oracle on the loaded texels;
 f4     the screenshot of a GPU frame (RM:762) is byte-identical to the screenshot of the oracle's frame, and the debug log /
        BVH dump carry the reference's counts (RM:331-335, 731-735; RD:92-117)."""
@@ -40,8 +41,8 @@ def registered_scene(width=160, height=96):
     return sc, objs
 
 
-@pytest.mark.parametrize("literal", [False, True])
-def test_registered_objects_through_cpp_flattening_render_like_the_oracle(gpu_ctx, tmp_path, literal):
+@pytest.mark.parametrize("literal,pairing", [(False, False), (True, False), (False, True)])
+def test_registered_objects_through_cpp_flattening_render_like_the_oracle(gpu_ctx, tmp_path, literal, pairing):
     sc, objs = registered_scene()
     m = RayTraceMaster(gpu_ctx, sc)
     m.rayDebug = RayTraceDebug(str(tmp_path), "log", 2)
@@ -51,7 +52,7 @@ def test_registered_objects_through_cpp_flattening_render_like_the_oracle(gpu_ct
     # OnRenderImage's rebuild branch (RM:850-859) with the literal / tight leaf boxes
     m._currentSample = 0
     m._treesNeedRebuilding = False
-    m.RebuildObjectLists(literal_leaf_bounds=literal)
+    m.RebuildObjectLists(literal_leaf_bounds=literal, pairing_heap=pairing)      # pairing: the reference's own heap builder (RM:459-722)
     m.RebuildTrees()
     for _ in range(3):
         m.OnRenderImage()
@@ -80,7 +81,7 @@ def test_registered_objects_through_cpp_flattening_render_like_the_oracle(gpu_ct
     mesh_dump, sphere_dump = m.OnDrawGizmos()
     md = open(mesh_dump).read().splitlines()
     assert len(md) == 7 and md[0].startswith("(0, -1) ")
-    leaf_ids = sorted(int(l.split(",")[1].split(")")[0]) for l in md if ", -1)" not in l)
+    leaf_ids = sorted(set(int(l.split(",")[1].split(")")[0]) for l in md if ", -1)" not in l))   # (the pairing builder repeats a lone tree's id on an interior position)
     assert leaf_ids == [0, 1, 2]
     assert len(open(sphere_dump).read().splitlines()) == 3
     m.OnDisable()

@@ -125,6 +125,61 @@ def _is_descendant(j, k):
     return j == k
 
 
+def _reachable(bvh):
+    """Object ids the traversal of RS:294-361 can reach: it descends only through nodes with index < 0."""
+    out, stack = [], [0]
+    while stack:
+        k = stack.pop()
+        if k >= len(bvh):
+            continue
+        if bvh[k]["index"] >= 0:
+            out.append((int(bvh[k]["index"]), k))
+        elif (bvh[k]["vmin"] != bvh[k]["vmax"]).any():
+            stack += [2 * k + 1, 2 * k + 2]
+    return out
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 8, 16, 37])
+def test_pairing_builder_heap_contract(built_library, n):
+    """The reference's own builder (RM:459-722, restated): complete implicit heap of 2^D - 1 nodes; every object is REACHED exactly
+    once (a lone tree's root keeps its object id on an interior position, RM:661-665: the copy below it is never visited); every
+    interior box holds the boxes of the objects reachable below it; deterministic."""
+    sp = scenes.make_spheres(n, 10.0, seed=100 + n)
+    for literal in (False, True):
+        leaves = host_scene.sphere_leaf_bounds(sp, literal=literal)
+        bvh = host_scene.build_object_bvh(leaves, pairing=True)
+        depth = 1 if n == 1 else int(np.ceil(np.log2(n))) + 1
+        assert len(bvh) == 2 ** depth - 1
+        reached = _reachable(bvh)
+        assert sorted(i for i, _ in reached) == list(range(n))
+        for i, k in reached:
+            assert same_bits(bvh[k]["vmin"], leaves[i]["vmin"]) and same_bits(bvh[k]["vmax"], leaves[i]["vmax"])
+            j = k
+            while j > 0:                                                   # every ancestor's box contains this object's box
+                j = (j - 1) // 2
+                lo, hi = np.minimum(leaves[i]["vmin"], leaves[i]["vmax"]), np.maximum(leaves[i]["vmin"], leaves[i]["vmax"])
+                assert (bvh[j]["vmin"] <= lo).all() and (bvh[j]["vmax"] >= hi).all()
+        assert same_bits(bvh, host_scene.build_object_bvh(leaves, pairing=True))
+
+
+def test_pairing_builder_known_answer(built_library):
+    """Three spheres on the x axis, A far left, B and C close together on the right.  With three nodes every pair has exactly one
+    bystander, whose centre lies on the line through the origin along the pair's axis: every distance is flipped to "forbidden"
+    (RM:546-552) and the ranking is by |distance| among them.  The only candidate that survives starts at index n-1 (RM:670
+    aliasing): round 1 pairs C with its nearest, B, and joins the lone A under a copy of itself; round 2 pairs those two trees.
+    JoinBVH weaves [A, A, filler] (the chooser's tree goes left on equal sizes) and [P, C, B] under the new root."""
+    sp = np.zeros(3, dtype=scenes.SPHERE_DT)
+    for k, x in enumerate((-3.0, 1.0, 2.5)):
+        sp[k]["position"] = (x, 0.0, 0.0); sp[k]["radius"] = 0.5
+    leaves = host_scene.sphere_leaf_bounds(sp, literal=False)
+    bvh = host_scene.build_object_bvh(leaves, pairing=True)
+    assert bvh["index"].tolist() == [-1, 0, -1, 0, -1, 2, 1]
+    assert bvh[0]["vmin"].tolist() == [-3.5, -0.5, -0.5] and bvh[0]["vmax"].tolist() == [3.0, 0.5, 0.5]
+    assert bvh[2]["vmin"].tolist() == [0.5, -0.5, -0.5] and bvh[2]["vmax"].tolist() == [3.0, 0.5, 0.5]      # P = B u C
+    assert (bvh[4]["vmin"] == 0).all() and (bvh[4]["vmax"] == 0).all()                                         # filler (RM:490-494)
+    assert sorted(i for i, _ in _reachable(bvh)) == [0, 1, 2]
+
+
 def test_images_do_not_depend_on_which_builder_made_the_heap(built_library):
     """Same pixels with the C++ heap (literal, quirky leaf boxes), the C++ heap (tight boxes) and scenes.py's numpy heap."""
     sc = scenes.mixed_test_scene(72, 48)
@@ -140,6 +195,13 @@ def test_images_do_not_depend_on_which_builder_made_the_heap(built_library):
         o2 = pyoracle.Oracle(s2)
         o2.set_blas(nodes, tri, root)
         assert np.array_equal(o2.render(mode=1, threads=8).view(np.uint32), want.view(np.uint32))
+    # ... and with the reference's own pairing builder (RM:459-722) on tight leaf boxes
+    s3 = copy.copy(sc)
+    s3.mesh_bvh = host_scene.build_object_bvh(host_scene.mesh_leaf_bounds(sc.mesh_objects, sc.vertices, sc.indices), pairing=True)
+    s3.sphere_bvh = host_scene.build_object_bvh(host_scene.sphere_leaf_bounds(sc.spheres), pairing=True)
+    o3 = pyoracle.Oracle(s3)
+    o3.set_blas(nodes, tri, root)
+    assert np.array_equal(o3.render(mode=1, threads=8).view(np.uint32), want.view(np.uint32))
 
 
 def test_register_objects_flattening_matches_scene_builder(built_library):

@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "urt_shader_set_int", "urt_shader_dispatch", "urt_shader_dispatch_rows", "urt_blit_add", "urt_blit", "urt_texture_pack_rows",
     "urt_texture_unpack_rows", "urt_texture_unpack_rows_on", "urt_set_option", "urt_get_counters", "urt_reset_counters", "urt_debug_build_blas", "urt_debug_get_blas", "urt_debug_blas_cache_stats",
     "urt_debug_scene_info", "urt_debug_read_scene_blas", "urt_host_compute_normals", "urt_host_mesh_leaf_bounds", "urt_host_sphere_leaf_bounds", "urt_host_object_bvh_length",
-    "urt_host_build_object_bvh", "urt_host_last_error", "urt_host_load_hdr", "urt_host_write_pfm", "urt_host_write_png",
+    "urt_host_build_object_bvh", "urt_host_build_object_bvh_pairing", "urt_host_last_error", "urt_host_load_hdr", "urt_host_write_pfm", "urt_host_write_png",
     "urt_host_resize_rgba", "urt_host_io_last_error", "urt_host_log", "urt_host_log_scene_counts", "urt_host_log_tree_report", "urt_host_dump_bvh",
     "urt_host_debug_last_error",
     "urt_group_create", "urt_group_destroy", "urt_group_size", "urt_group_context", "urt_group_last_error", "urt_group_buffer_create",
@@ -108,6 +108,7 @@ def load():
         "urt_host_sphere_leaf_bounds": ([vp, i, i, vp], i),
         "urt_host_object_bvh_length": ([i], i),
         "urt_host_build_object_bvh": ([vp, i, vp, i], i),
+        "urt_host_build_object_bvh_pairing": ([vp, i, vp, i], i),
         "urt_host_last_error": ([], C.c_char_p),
         "urt_host_load_hdr": ([C.c_char_p, pi, pi, vp, C.c_size_t], i),
         "urt_host_write_pfm": ([C.c_char_p, vp, i, i], i),

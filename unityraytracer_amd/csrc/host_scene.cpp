@@ -66,6 +66,153 @@ extern "C" {
 
 const char* urt_host_last_error(void) { return g_host_error.c_str(); }
 
+}  // extern "C"
+
+// ---- the reference's own object-level BVH builder, restated: SetupBVHRankList / PairBVHBounds / JoinBVH / CreateBVH (RM:459-722) ----
+// Literal, quirks included:
+//  * BVHNode equality is UnityEngine's APPROXIMATE Vector3 == (squared distance < 9.99999944e-11) on both corners plus the
+//    index (RM:153-155); `nodes.FindIndex(x => x == other)` is the first such node;
+//  * the "forbidden" test measures the distance of a bystander's centre from the line through the ORIGIN along the vector
+//    between the two centres (RM:546), and every bystander it catches FLIPS the sign of the distance (RM:550);
+//  * `bestPairing = pairing` (RM:670) aliases the list that every outer iteration clears, so the volume comparison is dead and
+//    the candidate built from start index n-1 always wins — all n candidates are still built here, as written;
+//  * a lone tree is joined with an empty list under a copy of its own root (RM:661-665): that object's id then also sits on an
+//    interior position, where the traversal treats it as a leaf (RS:311-318) and never descends further.
+// The one thing that cannot be restated is the ORDER OF TIES in ranking.Sort (RM:561): List<T>.Sort is an unstable introsort
+// whose tie order is the runtime's business.  Ties keep insertion order here (std::stable_sort) — "parity unpinned" for
+// scenes with exactly equal pair distances; pixels do not depend on the heap's shape (tests/test_host_scene.py).
+namespace {
+
+typedef std::vector<urt_BVHNode> Tree;
+
+inline bool unity_v3_equal(const float* a, const float* b) {          // UnityEngine.Vector3 operator ==
+  float x = a[0] - b[0], y = a[1] - b[1], z = a[2] - b[2];
+  return x * x + y * y + z * z < 9.99999944e-11f;
+}
+inline bool node_equal(const urt_BVHNode& a, const urt_BVHNode& b) {  // RM:153-155
+  return unity_v3_equal(b.vmax, a.vmax) && unity_v3_equal(b.vmin, a.vmin) && b.index == a.index;
+}
+inline int find_index(const std::vector<urt_BVHNode>& nodes, const urt_BVHNode& x) {
+  for (size_t i = 0; i < nodes.size(); i++) if (node_equal(nodes[i], x)) return (int)i;
+  return -1;
+}
+inline float magnitude(V3 v) { return (float)std::sqrt((double)(v.x * v.x + v.y * v.y + v.z * v.z)); }   // Vector3.Magnitude
+inline float sqr_magnitude(V3 v) { return v.x * v.x + v.y * v.y + v.z * v.z; }
+inline V3 centre(const urt_BVHNode& n) { return {(n.vmax[0] + n.vmin[0]) / 2.0f, (n.vmax[1] + n.vmin[1]) / 2.0f, (n.vmax[2] + n.vmin[2]) / 2.0f}; }
+inline float unity_sign(float f) { return f >= 0.0f ? 1.0f : -1.0f; }  // Mathf.Sign
+
+// RM:459-505
+Tree join_bvh(const urt_BVHNode& parent, const Tree* left, const Tree* right) {
+  double ll = left->empty() ? -INFINITY : std::log((double)left->size()) / std::log(2.0);
+  double lr = right->empty() ? -INFINITY : std::log((double)right->size()) / std::log(2.0);
+  int depth = (int)std::ceil((float)std::max((float)ll, (float)lr)) + 1;      // Mathf.CeilToInt(Mathf.Max(Mathf.Log(..,2), ..)) + 1
+  if (depth <= 1) depth = 2;
+  if (right->size() > left->size()) std::swap(left, right);
+  Tree list;
+  list.push_back(parent);
+  size_t start = 0, sub = 1;
+  urt_BVHNode filler;
+  std::memset(&filler, 0, sizeof filler); filler.index = -1;
+  for (int i = 1; i < depth; i++) {
+    for (size_t k = 0; k < sub; k++) list.push_back(start + k < left->size() ? (*left)[start + k] : filler);   // (left is complete in every call CreateBVH makes)
+    for (size_t k = 0; k < sub; k++) list.push_back(start + k < right->size() ? (*right)[start + k] : filler);
+    start += sub; sub *= 2;
+  }
+  return list;
+}
+
+// RM:510-595
+std::vector<std::vector<urt_BVHNode>> setup_rank_list(const std::vector<Tree>& trees) {
+  std::vector<urt_BVHNode> nodes;
+  for (const Tree& t : trees) nodes.push_back(t[0]);
+  std::vector<std::vector<urt_BVHNode>> rank_list;
+  struct Rank { int index; double dis; };
+  for (const urt_BVHNode& chosen : nodes) {
+    std::vector<Rank> ranking;
+    for (const urt_BVHNode& other : nodes) {
+      if (node_equal(chosen, other)) continue;                            // chosen != other
+      V3 a = {chosen.vmax[0] - other.vmin[0], chosen.vmax[1] - other.vmin[1], chosen.vmax[2] - other.vmin[2]};
+      V3 b = {chosen.vmin[0] - other.vmax[0], chosen.vmin[1] - other.vmax[1], chosen.vmin[2] - other.vmax[2]};
+      double distance = (double)std::min(sqr_magnitude(a), sqr_magnitude(b));
+      V3 test = sub(centre(chosen), centre(other));
+      if (magnitude(test) != 0) {
+        for (const urt_BVHNode& by : nodes) {
+          if (node_equal(by, chosen) || node_equal(by, other)) continue;
+          float line_dis = magnitude(cross(centre(by), test)) / magnitude(test);
+          V3 diag = {by.vmax[0] - by.vmin[0], by.vmax[1] - by.vmin[1], by.vmax[2] - by.vmin[2]};
+          if (line_dis <= magnitude(diag) / 2.0f) distance *= -1;
+        }
+      }
+      ranking.push_back({find_index(nodes, other), distance});
+    }
+    std::stable_sort(ranking.begin(), ranking.end(), [](const Rank& x, const Rank& y) {   // RM:561-580 as a strict "comes before"
+      if (x.dis == y.dis) return false;
+      if (unity_sign((float)x.dis) != unity_sign((float)y.dis)) return !(x.dis < y.dis);      // the negative ("forbidden") one goes last
+      if (x.dis < 0 || y.dis < 0) return -x.dis < -y.dis;
+      return x.dis < y.dis;
+    });
+    std::vector<urt_BVHNode> cur;
+    for (const Rank& r : ranking) cur.push_back(nodes[(size_t)r.index]);
+    rank_list.push_back(cur);
+  }
+  return rank_list;
+}
+
+// RM:598-678
+void pair_bvh_bounds(std::vector<Tree>& trees) {
+  std::vector<std::vector<urt_BVHNode>> rank_list = setup_rank_list(trees);
+  std::vector<Tree> pairing;                        // `bestPairing` is only ever an alias of this list
+  std::vector<urt_BVHNode> nodes;
+  for (const Tree& t : trees) nodes.push_back(t[0]);
+  const int num_tests = (int)nodes.size();
+  const Tree empty;
+  for (int i = 0; i < num_tests; i++) {
+    pairing.clear();
+    std::vector<char> paired(nodes.size(), 0);
+    for (int j = i; j < i + num_tests; j++) {
+      int index = j % (int)trees.size();
+      if (paired[(size_t)index]) continue;
+      for (size_t k = 0; k < rank_list[(size_t)index].size(); k++) {
+        int other = find_index(nodes, rank_list[(size_t)index][k]);
+        if (other >= 0 && !paired[(size_t)other]) {
+          paired[(size_t)index] = 1; paired[(size_t)other] = 1;
+          const urt_BVHNode& p = nodes[(size_t)index]; const urt_BVHNode& q = nodes[(size_t)other];
+          urt_BVHNode parent;
+          for (int c = 0; c < 3; c++) {             // RM:642-647: min / max over BOTH corners of both boxes
+            parent.vmin[c] = std::min(std::min(p.vmin[c], q.vmin[c]), std::min(p.vmax[c], q.vmax[c]));
+            parent.vmax[c] = std::max(std::max(p.vmin[c], q.vmin[c]), std::max(p.vmax[c], q.vmax[c]));
+          }
+          parent.index = -1;
+          pairing.push_back(join_bvh(parent, &trees[(size_t)index], &trees[(size_t)other]));
+          break;
+        }
+      }
+      if (!paired[(size_t)index]) pairing.push_back(join_bvh(nodes[(size_t)index], &trees[(size_t)index], &empty));   // RM:661-665
+    }
+  }
+  trees = pairing;                                  // RM:677 (the candidate of the last start index)
+}
+
+}  // namespace
+
+extern "C" {
+
+int urt_host_build_object_bvh_pairing(const urt_BVHNode* leaves, int n_objects, urt_BVHNode* out_nodes, int capacity) {
+  int len = urt_host_object_bvh_length(n_objects);
+  if (n_objects < 0 || (n_objects && (!leaves || !out_nodes)) || capacity < len) return host_fail(URT_ERR_INVALID_ARGUMENT, "CreateBVH: bad arguments");
+  if (n_objects == 0) return URT_OK;                 // (the reference throws on an empty list, A.7; an empty list is "no buffer" here)
+  try {
+    int depth = 1;
+    while ((1 << (depth - 1)) < n_objects) depth++;  // RM:683,705: Mathf.CeilToInt(Mathf.Log(n, 2)) + 1
+    std::vector<Tree> trees((size_t)n_objects);
+    for (int i = 0; i < n_objects; i++) trees[(size_t)i].push_back(leaves[i]);
+    for (int i = 0; i < depth - 1; i++) pair_bvh_bounds(trees);
+    if (trees.empty() || (int)trees[0].size() != len) return host_fail(URT_ERR_SCENE, "CreateBVH: the pairing did not end in one complete tree");
+    std::memcpy(out_nodes, trees[0].data(), sizeof(urt_BVHNode) * (size_t)len);
+    return URT_OK;
+  } catch (...) { return host_fail(URT_ERR_OUT_OF_MEMORY, "CreateBVH: allocation failed"); }
+}
+
 int urt_host_compute_normals(const float* vertices, int n_vertices, const int32_t* indices, int n_indices, float* out_normals) {
   if (n_vertices < 0 || n_indices < 0 || n_indices % 3 != 0) return host_fail(URT_ERR_INVALID_ARGUMENT, "ComputeNormals: bad counts");
   if ((n_vertices && (!vertices || !out_normals)) || (n_indices && !indices)) return host_fail(URT_ERR_INVALID_ARGUMENT, "ComputeNormals: NULL array");

@@ -50,11 +50,13 @@ def sphere_leaf_bounds(spheres, literal: bool = False) -> np.ndarray:
     return out
 
 
-def build_object_bvh(leaves: np.ndarray) -> np.ndarray:
-    """Implicit-heap object BVH in the format CreateBVH emits (RM:681-722) from per-object leaf boxes."""
+def build_object_bvh(leaves: np.ndarray, pairing: bool = False) -> np.ndarray:
+    """Implicit-heap object BVH in the format CreateBVH emits (RM:681-722) from per-object leaf boxes.  pairing=True runs the
+    reference's own builder (SetupBVHRankList / PairBVHBounds / JoinBVH, RM:459-678, restated literally) instead of the median split."""
     lib = _lib.load()
     lv = np.ascontiguousarray(leaves, dtype=BVHNODE_DT)
     n = lib.urt_host_object_bvh_length(len(lv))
     out = np.zeros(n, dtype=BVHNODE_DT)
-    _check(lib, lib.urt_host_build_object_bvh(_p(lv), len(lv), _p(out), n))
+    fn = lib.urt_host_build_object_bvh_pairing if pairing else lib.urt_host_build_object_bvh
+    _check(lib, fn(_p(lv), len(lv), _p(out), n))
     return out

@@ -79,7 +79,7 @@ class RayTraceMaster:
 
     # RM:262-336 — flatten the registered objects into the lists the buffers are made from; normals (RM:340-368) and the
     # object-level BVHs (RM:405-722 output contract) come from the C++ host library (csrc/host_scene.cpp)
-    def RebuildObjectLists(self, literal_leaf_bounds: bool = False):
+    def RebuildObjectLists(self, literal_leaf_bounds: bool = False, pairing_heap: bool = False):
         s = self.scene
         spheres, mesh_objects, verts, idx = [], [], [], []
         nv = ni = 0
@@ -105,9 +105,9 @@ class RayTraceMaster:
         s.indices = np.concatenate(idx).astype(np.int32) if idx else np.zeros(0, np.int32)
         s.normals = host_scene.compute_normals(s.vertices, s.indices)            # RM:328
         # CreateBVH(_meshObjects) / CreateBVH(_spheres), RM:727-728 (the reference throws on an empty list, A.7; here empty = no buffer)
-        s.mesh_bvh = host_scene.build_object_bvh(host_scene.mesh_leaf_bounds(s.mesh_objects, s.vertices, s.indices, literal_leaf_bounds)) \
+        s.mesh_bvh = host_scene.build_object_bvh(host_scene.mesh_leaf_bounds(s.mesh_objects, s.vertices, s.indices, literal_leaf_bounds), pairing_heap) \
             if len(s.mesh_objects) else np.zeros(0, scenes.BVHNODE_DT)
-        s.sphere_bvh = host_scene.build_object_bvh(host_scene.sphere_leaf_bounds(s.spheres, literal_leaf_bounds)) \
+        s.sphere_bvh = host_scene.build_object_bvh(host_scene.sphere_leaf_bounds(s.spheres, literal_leaf_bounds), pairing_heap) \
             if len(s.spheres) else np.zeros(0, scenes.BVHNODE_DT)
         if getattr(self, "rayDebug", None) is not None:                             # RM:331-335
             self.rayDebug.LogSceneCounts(len(s.spheres), len(s.mesh_objects), len(s.vertices), len(s.indices), len(s.normals))
