@@ -493,7 +493,7 @@ extern "C" {
 int oracle_render(const OracleScene* scene, int x0, int y0, int x1, int y1, int mode, int n_threads,
                   float* out, OracleCounters* counters) {
   if (!scene || !out || x0 < 0 || y0 < 0 || x1 > scene->width || y1 > scene->height || x0 > x1 || y0 > y1) return 1;
-  if (mode == 1 && scene->n_mesh_objects > 0 && (!scene->blas_nodes && scene->n_blas_nodes > 0)) return 1;
+  if (mode == 1 && scene->n_mesh_objects > 0 && (!scene->blas_nodes || !scene->blas_tri_index || !scene->blas_mesh_root || scene->n_blas_nodes <= 0)) return 1;   // mode 1 walks the triangle BVH: it must be there
   if (n_threads < 1) n_threads = 1;
   std::vector<OracleCounters> cs((size_t)n_threads);
   auto work = [&](int tid) {

@@ -63,3 +63,16 @@ def test_product_never_touches_the_oracle():
                 assert not bad.search(text), f"{f} references the oracle"
     for f in os.listdir(os.path.join(ROOT, "include")):
         assert not bad.search(open(os.path.join(ROOT, "include", f)).read()), f
+
+
+def test_header_is_plain_c99_and_the_c_example_compiles(tmp_path):
+    """include/urt.h is the drop-in boundary: it must parse as C (not only C++), warning-free, and examples/frame_loop.c — the
+    reference's frame protocol written in C99 against it — must compile (linking/running it needs the GPU: tests/test_gpu_c_host.py)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    inc = "-I" + os.path.join(root, "include")
+    (tmp_path / "only_header.c").write_text('#include "urt.h"\nint urt_header_probe(void) { return (int)sizeof(urt_counters); }\n')
+    for std in ("-std=c99", "-std=c11"):
+        subprocess.run(["gcc", std, "-pedantic", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", inc, str(tmp_path / "only_header.c")], check=True)
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "frame_loop.c")], check=True)
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", inc, "-x", "c++", str(tmp_path / "only_header.c")], check=True)

@@ -9,6 +9,7 @@
    and counts the cases where BVH-culled traversal (the product's BVH and the oracle's own) and literal brute force
    (RS:243-266) disagree."""
 import numpy as np
+import pytest
 
 from oracle import pyoracle
 from unityraytracer_amd import debug_build_blas, scenes
@@ -93,3 +94,12 @@ def test_grazing_rays_bvh_never_culls_a_moller_trumbore_hit():
           f"BVH-culled vs brute-force disagreements (two BVHs): {mismatches}")
     assert grazed_hits > n_rays // 4                       # the construction really produces near-threshold hits
     assert mismatches == 0                                 # DESIGN.md §4 quotes this count
+
+
+def test_oracle_refuses_bvh_mode_without_a_triangle_bvh():
+    """mode 1 walks the triangle BVH handed over with set_blas; asking for it on a mesh scene without one is an argument error."""
+    sc = scenes.mixed_test_scene(16, 8)
+    o = pyoracle.Oracle(sc)
+    with pytest.raises(ValueError):
+        o.render(mode=1)
+    assert np.isfinite(o.render(mode=0)).all()
