@@ -306,6 +306,9 @@ URT_API int urt_debug_read_scene_blas(urt_context* ctx, float* nodes, int32_t* t
  * MeshObject's matrix and the positions behind its index slots are unchanged (the reference re-uploads every buffer when
  * any object moves, RM:262-336).  Reports how many MeshObject BVHs were reused / built since the context was created. */
 URT_API int urt_debug_blas_cache_stats(urt_context* ctx, uint64_t* out_reused, uint64_t* out_built);
+/* kernel_mode 5 with "count_stats" = 1: what the shared traversal service did since the last urt_reset_counters —
+ * out6 = visits of the service, its trips, active lanes summed over the trips, claim rounds, rays claimed, rays suspended. */
+URT_API int urt_debug_serve_stats(urt_context* ctx, unsigned long long* out6);
 
 #ifdef __cplusplus
 }

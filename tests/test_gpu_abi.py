@@ -53,7 +53,7 @@ def test_empty_scene_and_zero_loops(gpu_ctx):
     """No buffers bound at all: ground plane + sky only (RS:375-379 treat missing buffers as count 0)."""
     sc = scenes.Scene("empty", 100, 60, 3, 2, sky=scenes.make_sky(64, 32))
     ref = pyoracle.Oracle(sc).render(threads=4)
-    for mode in (0, 1, 2, 3, 4):
+    for mode in (0, 1, 2, 3, 4, 5):
         gpu_ctx.set_option("kernel_mode", mode)
         m = RayTraceMaster(gpu_ctx, sc)
         m.OnRenderImage()

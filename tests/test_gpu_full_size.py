@@ -51,7 +51,7 @@ def test_full_size_config_bit_exact(gpu_ctx, cfg):
     assert gc["pixels"] == sc.width * sc.height and gc["watchdog_trips"] == 0
     # the frame does not depend on the kernel mode (same hash from the per-pixel and the persistent-regeneration kernels)
     h3 = hashlib.sha256(img.tobytes()).hexdigest()
-    for mode in ((0, 2, 4) if cfg in ("C2", "C3") else (2, 4)):
+    for mode in ((0, 2, 4, 5) if cfg in ("C2", "C3") else (2, 4, 5)):
         gpu_ctx.set_option("kernel_mode", mode)
         m._frame = 0
         m._currentSample = 0

@@ -14,7 +14,7 @@ make_golden = importlib.util.module_from_spec(spec)
 
 
 @pytest.mark.parametrize("name", ["c1_crop", "mixed_frame", "multi_ray_accum", "c3_crop"])
-@pytest.mark.parametrize("mode", [4, 3, 2, 1, 0])
+@pytest.mark.parametrize("mode", [5, 4, 3, 2, 1, 0])
 def test_hip_matches_golden(gpu_ctx, name, mode):
     spec.loader.exec_module(make_golden)
     scene, rect, _, frames = make_golden.cases()[name]

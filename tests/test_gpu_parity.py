@@ -43,7 +43,7 @@ def oracle_for(scene, use_product_blas=True):
     return o
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 5])
 def test_mixed_scene_bit_exact(gpu_ctx, mode):
     sc = scenes.mixed_test_scene(200, 120)           # ragged: not a multiple of 8
     o = oracle_for(sc)
@@ -115,7 +115,7 @@ def test_many_meshes_beyond_the_lds_tables(gpu_ctx):
     sc = scenes.many_meshes_scene(128, 80)
     o = oracle_for(sc)
     ref, oc = o.render(mode=1, threads=8, counters=True)
-    for mode in (0, 1, 2, 3, 4):
+    for mode in (0, 1, 2, 3, 4, 5):
         gpu, _, gc = render_gpu(gpu_ctx, sc, mode, count=True)
         assert_same(gpu, ref, f"many meshes, mode {mode}")
         for k in ("rays", "tlas_nodes", "blas_nodes", "tri_tests", "hit_tri", "hit_ground", "hit_sky", "pixels"):
@@ -169,7 +169,7 @@ def test_multi_ray_multi_frame_accumulation(gpu_ctx):
         ox, oy, seed = scenes.frame_uniforms(f)
         o.set_frame((ox, oy), seed)
         conv_ref = pyoracle.accumulate(o.render(mode=1, threads=8), conv_ref, f)
-    for mode in (0, 1, 2, 3, 4):
+    for mode in (0, 1, 2, 3, 4, 5):
         _, conv, _ = render_gpu(gpu_ctx, sc, mode, frames=3)
         assert_same(conv, conv_ref, f"3-frame running mean, mode {mode}")
 
@@ -210,3 +210,35 @@ def test_strips_union_equals_full_frame(gpu_ctx):
         assert not part[~own].any()
         m.OnDisable()
     assert_same(union, full, "union of strips")
+
+
+def test_shared_traversal_service_mode5(gpu_ctx):
+    """kernel_mode 5: paths post the rays that must enter a triangle BVH to their workgroup's mailbox; any wave of the workgroup
+    claims them, walks them on its idle lanes, answers or suspends them.  Pixels and every counter equal the oracle's whatever
+    the service thresholds — including entry thresholds below the yield threshold (a visit always advances its rays one trip)
+    and refill on every idle lane — on one mesh, on several (rays suspended mid-BVH resume on another wave) and with _numRays 3."""
+    cases = [(scenes.config3(256, 160), {}), (scenes.config3(256, 160), {"blas_min": 8, "blas_exit": 40, "serve_refill": 1}),
+             (scenes.config3(256, 160), {"blas_min": 200, "blas_exit": 1, "serve_refill": 64}), (scenes.many_meshes_scene(128, 80), {"blas_min": 16, "blas_exit": 32})]
+    multi = scenes.mixed_test_scene(96, 64); multi.num_rays = 3
+    cases.append((multi, {}))
+    try:
+        for sc, opts in cases:
+            o = oracle_for(sc)
+            ref, oc = o.render(mode=1, threads=8, counters=True)
+            for k, v in opts.items():
+                gpu_ctx.set_option(k, v)
+            gpu, _, gc = render_gpu(gpu_ctx, sc, 5, count=True)
+            sv = gpu_ctx.serve_stats()
+            for k, v in {"blas_min": 28, "blas_exit": 0, "serve_refill": 16}.items():
+                gpu_ctx.set_option(k, v)
+            assert_same(gpu, ref, f"mode 5 {sc.name} {opts}")
+            for k in ("rays", "tlas_nodes", "blas_nodes", "tri_tests", "hit_tri", "hit_ground", "hit_sky", "pixels"):
+                assert gc[k] == oc[k], (opts, k, gc[k], oc[k])
+            assert gc["watchdog_trips"] == 0
+            assert sv["visits"] > 0 and sv["claimed"] > 0 and sv["lane_trips"] >= sv["trips"] > 0, sv
+            if opts.get("blas_exit", 0) >= 32:
+                assert sv["suspended"] > 0, sv                   # the yield path (suspend -> resumed by any wave) really ran
+    finally:
+        for k, v in {"blas_min": 28, "blas_exit": 0, "serve_refill": 16}.items():
+            gpu_ctx.set_option(k, v)
+        gpu_ctx.set_option("kernel_mode", 3); gpu_ctx.set_option("count_stats", 0)

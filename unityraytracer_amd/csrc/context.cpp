@@ -95,6 +95,7 @@ struct urt_context {
 
   DevCounters* d_counters = nullptr;        // kCounterShards shards
   unsigned int* d_next = nullptr;           // persistent mode: frame work counter
+  float4* d_mail = nullptr; size_t mail_slots = 0;   // kernel_mode 5: posted rays (2 float4 per thread of the resident grid)
   uint64_t pixels_dispatched = 0;
   int n_cus = 256;
 
@@ -108,6 +109,7 @@ struct urt_context {
   int opt_sched_block = 0;                  // kernel_mode 3: threads per workgroup (64 or 256; 0 = 256 when there is a BVH top to share)
   int opt_stack_pad = 0;                    // test hook: extra (unused) entries per traversal stack, to reach the > 64 KiB LDS launch path
   int opt_shade_min = 32, opt_sky_min = 32; // kernel_mode 3
+  int opt_serve_refill = 16;                // kernel_mode 5: idle lanes of the traversal service that trigger a claim of waiting rays
   int opt_front_list = -1;                  // kernel_mode 3: listed FRONT for scenes of <= 12 MeshObjects (-1 auto = on, 0 off)
   int opt_shade_split = -1;                 // kernel_mode 3: -1 = auto (= split: measured better or equal on C2-C5), 0 = surface hits and misses shaded in one trip
   int opt_tile_order = 0;                   // persistent modes: order in which the frame's tiles are handed out
@@ -477,8 +479,10 @@ int configure_sched(urt_context* ctx, const DevScene& S, FrameParams& P, bool to
   P.lds_sphere = ctx->opt_lds_tlas && S.n_sphere_tlas > 0 && S.n_sphere_tlas <= 256 && S.n_spheres <= 256;
   bool shared = t > 0 || P.lds_mesh || P.lds_sphere;
   P.block_threads = ctx->opt_sched_block > 0 ? ctx->opt_sched_block : (shared ? 256 : 64);   // nothing to share: single waves
+  if (P.serve) P.block_threads = 256;                        // kernel_mode 5: the waves of a workgroup share the traversal service
   P.top_nodes = t;
-  size_t groups = std::max<size_t>(1, (size_t)(ctx->opt_waves_per_cu > 0 ? ctx->opt_waves_per_cu : 20) / (size_t)(P.block_threads / 64));   // workgroups per CU that must fit
+  const int wpc_default = P.serve ? 16 : 20;                 // what the kernel's registers allow (k_serve: 128 VGPRs, k_sched: 96)
+  size_t groups = std::max<size_t>(1, (size_t)(ctx->opt_waves_per_cu > 0 ? ctx->opt_waves_per_cu : wpc_default) / (size_t)(P.block_threads / 64));   // workgroups per CU that must fit
   const size_t budget = 156 * 1024;                          // (a little of the 160 KiB goes to allocation granules)
   while (P.top_nodes > 0 && sched_lds_bytes(S, P) * groups > budget) P.top_nodes /= 2;
   if (sched_lds_bytes(S, P) * groups > budget) { P.lds_mesh = 0; P.lds_sphere = 0; P.lds_small = 0; }
@@ -497,16 +501,25 @@ int launch_sched_frames(urt_context* ctx, const DevScene& S, const FrameParams& 
   // frame's work counter was one address, fewer and fatter waves were faster at 1080p (12 per CU); since it is sharded
   // (kernels.hip wave_fetch_pixels) the full 20 win at every frame size measured (profiles/README.md).
   int wpc = ctx->opt_waves_per_cu;
-  if (wpc <= 0) wpc = 20;
+  if (wpc <= 0) wpc = P.serve ? 16 : 20;
   long resident = (long)ctx->n_cus * wpc / waves_per_block;
   int nb = (int)std::max(1L, std::min(want, resident));
+  if (P.serve) {                                             // mailbox of the posted rays: 32 B per thread of the grid
+    size_t slots = (size_t)nb * (size_t)P.block_threads;
+    if (slots > ctx->mail_slots) {
+      if (ctx->d_mail) { URT_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->d_mail); ctx->d_mail = nullptr; ctx->mail_slots = 0; }
+      URT_HIP(ctx, hipMalloc((void**)&ctx->d_mail, slots * 2 * sizeof(float4)));
+      ctx->mail_slots = slots;
+    }
+  }
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ctx->opt_time_dispatch) {
     int rc = take_event(ctx, &e0); if (rc) return rc;
     rc = take_event(ctx, &e1); if (rc) return rc;
     URT_HIP(ctx, hipEventRecord(e0, ctx->stream));
   }
-  hipError_t le = launch_sched(S, P, T, result, ctx->d_counters, ctx->d_next, nb, front_mode, count, ctx->stream);
+  hipError_t le = P.serve ? launch_serve(S, P, T, result, ctx->d_counters, ctx->d_next, ctx->d_mail, nb, front_mode, count, ctx->stream)
+                          : launch_sched(S, P, T, result, ctx->d_counters, ctx->d_next, nb, front_mode, count, ctx->stream);
   if (ctx->opt_time_dispatch) {
     (void)hipEventRecord(e1, ctx->stream);
     ctx->timing.emplace_back(e0, e1);
@@ -636,13 +649,15 @@ int do_dispatch(urt_context* ctx, int kernel, int gx, int gy, int gz, int first_
   }
   bool degenerate = P.num_bounces <= 0 || P.num_rays <= 0;      // loops that never run: the megakernel handles them literally
   int mode = degenerate ? 0 : ctx->opt_kernel_mode;
-  if (mode == 3 && P.num_bounces >= (1 << 24)) mode = 2;        // k_sched keeps the bounce index in 24 bits
+  if ((mode == 3 || mode == 5) && P.num_bounces >= (1 << 24)) mode = 2;        // k_sched / k_serve keep the bounce index in 24 bits
   bool count = ctx->opt_count_stats != 0;
   const int region[4] = {P.region_w, P.region_h, first_row, row_stride};
   const bool full_cover = P.region_w == res->w && P.region_h == res->h && first_row == 0 && row_stride == 1;
 
-  if (mode == 3) {
+  if (mode == 3 || mode == 5) {
     bool top_in_front = ctx->opt_top_front < 0 ? S.n_meshes > 1 : ctx->opt_top_front != 0;
+    P.serve = mode == 5 && ctx->n_blas_nodes > 0;            // no triangle BVH, nothing to serve: mode 3's kernel
+    P.pool_inloop = ctx->opt_serve_refill;
     int front_mode = configure_sched(ctx, S, P, top_in_front);
     P.shade_split = ctx->opt_shade_split != 0;
     FrameUniforms fu{};
@@ -658,7 +673,7 @@ int do_dispatch(urt_context* ctx, int kernel, int gx, int gy, int gz, int first_
     if (B.n > 0) {
       const FrameParams& Q = B.P;
       bool same = B.tex == res_h && B.scene_epoch == ctx->scene_epoch && B.S.sky == S.sky && B.S.sky_w == S.sky_w && B.S.sky_h == S.sky_h &&
-                  B.count == count && B.front_mode == front_mode && Q.num_bounces == P.num_bounces && Q.num_rays == P.num_rays &&
+                  B.count == count && B.front_mode == front_mode && Q.serve == P.serve && Q.num_bounces == P.num_bounces && Q.num_rays == P.num_rays &&
                   Q.width == P.width && Q.height == P.height && Q.region_w == P.region_w && Q.region_h == P.region_h &&
                   Q.first_group_row == P.first_group_row && Q.row_stride == P.row_stride && B.n < B.limit && limit > 1;
       if (!same) { int rc = flush_pending(ctx); if (rc) return rc; }
@@ -786,6 +801,7 @@ int urt_context_destroy(urt_context* ctx) {
   if (ctx->zero_sky) (void)hipFree(ctx->zero_sky);
   if (ctx->d_counters) (void)hipFree(ctx->d_counters);
   if (ctx->d_next) (void)hipFree(ctx->d_next);
+  if (ctx->d_mail) (void)hipFree(ctx->d_mail);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
   return URT_OK;
@@ -1137,7 +1153,7 @@ int urt_set_option(urt_context* ctx, const char* name, int value) {
   } else if (std::strcmp(name, "count_stats") == 0) ctx->opt_count_stats = value ? 1 : 0;
   else if (std::strcmp(name, "time_dispatch") == 0) ctx->opt_time_dispatch = value ? 1 : 0;
   else if (std::strcmp(name, "kernel_mode") == 0) {
-    if (value < 0 || value > 4) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "kernel_mode must be 0..4");
+    if (value < 0 || value > 5) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "kernel_mode must be 0..5");
     ctx->opt_kernel_mode = value;
   } else if (std::strcmp(name, "block_threads") == 0) {
     if (value != 64 && value != 128 && value != 256) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "block_threads must be 64, 128 or 256");
@@ -1147,7 +1163,7 @@ int urt_set_option(urt_context* ctx, const char* name, int value) {
     set_blas_leaf_max(value);
     ctx->scene_dirty = true;
   } else if (std::strcmp(name, "blas_min") == 0) {
-    if (value < 1 || value > 64) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "blas_min must be in [1, 64]");
+    if (value < 1 || value > 256) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "blas_min must be in [1, 256] (kernel_mode 5 counts the waiting rays of a workgroup)");
     ctx->opt_blas_min = value;
   } else if (std::strcmp(name, "blas_exit") == 0) {
     if (value < 0 || value > 64) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "blas_exit must be in [0, 64] (0 = auto)");
@@ -1173,6 +1189,9 @@ int urt_set_option(urt_context* ctx, const char* name, int value) {
   } else if (std::strcmp(name, "shade_split") == 0) {
     if (value < -1 || value > 1) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "shade_split must be -1 (auto), 0 or 1");
     ctx->opt_shade_split = value;
+  } else if (std::strcmp(name, "serve_refill") == 0) {
+    if (value < 1 || value > 64) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "serve_refill must be in [1, 64]");
+    ctx->opt_serve_refill = value;
   } else if (std::strcmp(name, "sky_min") == 0) {
     if (value < 1 || value > 64) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "sky_min must be in [1, 64]");
     ctx->opt_sky_min = value;
@@ -1258,6 +1277,21 @@ __attribute__((visibility("default"))) int urt_debug_read_stamps(urt_context* ct
   return (int)e;
 }
 #endif
+
+/* kernel_mode 5 with count_stats: visits of the traversal service, its trips, active lanes summed over the trips, claim rounds,
+   rays claimed, rays suspended — summed since the last urt_reset_counters */
+int urt_debug_serve_stats(urt_context* ctx, unsigned long long* out6) {
+  if (!ctx) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  if (!out6) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "out6 is NULL");
+  URT_HIP(ctx, hipSetDevice(ctx->device));
+  { int rc = flush_pending(ctx); if (rc) return rc; }
+  URT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  std::vector<DevCounters> shards(kCounterShards);
+  URT_HIP(ctx, hipMemcpy(shards.data(), ctx->d_counters, sizeof(DevCounters) * kCounterShards, hipMemcpyDeviceToHost));
+  for (int q = 0; q < 6; q++) out6[q] = 0;
+  for (const DevCounters& dc : shards) for (int q = 0; q < 6; q++) out6[q] += dc.serve[q];
+  return URT_OK;
+}
 
 /* ---- introspection ---- */
 int urt_debug_build_blas(const void* mesh_objects, int n_meshes, const float* vertices, int n_vertices, const int32_t* indices,

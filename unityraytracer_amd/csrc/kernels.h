@@ -19,6 +19,10 @@ hipError_t launch_persist(const DevScene& S, const FrameParams& P, float4* resul
 // 2 = listed form of 1 (needs P.lds_mesh and n_meshes <= 12)
 hipError_t launch_sched(const DevScene& S, const FrameParams& P, const FrameTable& T, float4* result, DevCounters* ctr,
                         unsigned int* next, int n_blocks, int front_mode, bool count, hipStream_t st);
+// mode 5: mode 3 with the triangle-BVH phase as a service shared by the 4 waves of a workgroup (k_serve); `mail` = 2 float4 per
+// thread of the grid (ray origin / direction of the posted rays); needs P.serve = 1 and P.block_threads = 256
+hipError_t launch_serve(const DevScene& S, const FrameParams& P, const FrameTable& T, float4* result, DevCounters* ctr,
+                        unsigned int* next, float4* mail, int n_blocks, int front_mode, bool count, hipStream_t st);
 // fused AdditionShader blends of n consecutive frames into one image: dst = blend(... blend(blend(dst, src_0), src_1) ..., src_{n-1})
 // in that order per pixel — the same operations as n launch_blit_add calls; src_f = src + f * frame_stride
 hipError_t launch_blit_add_multi(const float4* src, size_t frame_stride, int n, const float* samples, float4* dst, size_t n_pixels,

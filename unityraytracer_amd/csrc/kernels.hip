@@ -191,6 +191,33 @@ __device__ __forceinline__ int32_t blas_node_eval(float4 q0, float4 q1, float4 q
   return blas_pop(stk, sp);
 }
 
+// The same step without branches (the traversal loop of k_sched: per-wave instruction count is what bounds it, and the three-way
+// branch of blas_node_eval costs a dozen scalar instructions per trip): the would-be pop value is read ahead (the LDS read
+// overlaps the node fetch), the far child is written to the free slot above the stack top whether or not it is pushed (slot
+// sp <= depth of the tree always exists: the stack has depth + 1 entries), and cursor / height are selected.
+__device__ __forceinline__ int32_t blas_node_eval_flat(float4 q0, float4 q1, float4 q2, float4 q3, const BlasRay& R, float tbest, int* stk, int& sp) {
+  int below = stk[max(sp - 1, 0) * 64];
+  float a1x = f_fma(q0.x, R.idir.x, R.nop.x), a2x = f_fma(q0.w, R.idir.x, R.nom.x);
+  float a1y = f_fma(q0.y, R.idir.y, R.nop.y), a2y = f_fma(q1.x, R.idir.y, R.nom.y);
+  float a1z = f_fma(q0.z, R.idir.z, R.nop.z), a2z = f_fma(q1.y, R.idir.z, R.nom.z);
+  float tn0 = f_max(f_max(f_min(a1x, a2x), f_min(a1y, a2y)), f_max(f_min(a1z, a2z), 0.0f));
+  float tf0 = f_min(f_min(f_max(a1x, a2x), f_max(a1y, a2y)), f_min(f_max(a1z, a2z), tbest));
+  float b1x = f_fma(q1.z, R.idir.x, R.nop.x), b2x = f_fma(q2.y, R.idir.x, R.nom.x);
+  float b1y = f_fma(q1.w, R.idir.y, R.nop.y), b2y = f_fma(q2.z, R.idir.y, R.nom.y);
+  float b1z = f_fma(q2.x, R.idir.z, R.nop.z), b2z = f_fma(q2.w, R.idir.z, R.nom.z);
+  float tn1 = f_max(f_max(f_min(b1x, b2x), f_min(b1y, b2y)), f_max(f_min(b1z, b2z), 0.0f));
+  float tf1 = f_min(f_min(f_max(b1x, b2x), f_max(b1y, b2y)), f_min(f_max(b1z, b2z), tbest));
+  bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
+  int32_t c0 = as_int(q3.x), c1 = as_int(q3.y);
+  bool both = h0 && h1, none = !h0 && !h1;
+  bool first1 = h1 && (!h0 || tn1 < tn0);          // child 1 is visited first: the only hit, or the nearer of two (ties: child 0)
+  stk[sp * 64] = first1 ? c0 : c1;                  // the far child, where a push would put it
+  int32_t popped = sp > 0 ? below : kBlasDone;
+  int32_t nxt = none ? popped : (first1 ? c1 : c0);
+  sp += both ? 1 : (none && sp > 0 ? -1 : 0);
+  return nxt;
+}
+
 // One interior-node step: slab-test both children against [0, tbest], descend into the nearer hit child (ties: child 0),
 // push the other; returns the next cursor.
 template <bool COUNT>
@@ -209,7 +236,7 @@ __device__ __forceinline__ int32_t blas_node_step_top(const float4* top, int32_t
                                                       LocalCounters& lc) {
   if (COUNT) lc.blas_nodes++;
   const float4* n = top + 4 * cur;
-  return blas_node_eval(n[0], n[1], n[2], n[3], R, tbest, stk, sp);
+  return blas_node_eval_flat(n[0], n[1], n[2], n[3], R, tbest, stk, sp);
 }
 
 template <bool COUNT>
@@ -616,7 +643,7 @@ __device__ __forceinline__ bool wave_fetch_pixels(const FrameParams& P, unsigned
   unsigned int own = shard_slots(ntiles, wc.shard, G);
   unsigned int base = 0;
   if (lane == 0) base = atomicAdd(next + wc.shard * 32u, n);
-  base = __shfl(base, 0, 64);
+  base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);   // called by the whole wave: lane 0's value, and wave-uniform for the compiler (what hangs off it — shard moves, `exhausted` — stays in scalar registers)
   unsigned int shard = wc.shard;
   if (base + n >= own) {   // this shard is (now) dry: every lane looks at one counter, the wave moves to the next shard with work
     unsigned int seen = __hip_atomic_load(next + lane * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1106,29 +1133,36 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
       if (mine && cur >= 0 && cur < P.top_nodes) {
         do cur = blas_node_step_top<COUNT>(top, cur, R, best.t, bl, sp, lc); while (cur >= 0 && cur < P.top_nodes);
       }
-      bool active = mine && cur != kBlasDone;
-      int budget = (int)min(P.watchdog_steps, 0x7fffffffu);     // trips left before the watchdog ends this phase (counted down: no kernel argument in the loop)
+      // The loop works on ONE integer per lane: c = the cursor of the lanes that take part, kBlasDone for every other lane.  Both
+      // votes are then single compares whose result IS the ballot (kBlasDone is negative, so c >= 0 <=> an interior node of a
+      // participating lane), and the loop control sits in scalar registers (the limits are pinned there).
+      int32_t c = mine ? cur : kBlasDone;
+      int budget = __builtin_amdgcn_readfirstlane((int)min(P.watchdog_steps, 0x7fffffffu));   // trips left before the watchdog ends this phase (counted down: no kernel argument in the loop)
+      const int exit_s = __builtin_amdgcn_readfirstlane(exit_below);
       for (;;) {
-        unsigned long long mA = wballot(active);
-        if (__popcll(mA) < exit_below) break;
+        int nA = __popcll(wballot(c != kBlasDone));
+        if (nA < exit_s) break;
         if (--budget < 0) { watchdog = true; break; }
 #ifdef URT_STAMPS
-        ph_trips[3]++; ph_lanes[3] += (unsigned long long)__popcll(mA);
-        if (exhausted) { dr_trips[3]++; dr_lanes3 += (unsigned long long)__popcll(mA); }
+        ph_trips[3]++; ph_lanes[3] += (unsigned long long)nA;
+        if (exhausted) { dr_trips[3]++; dr_lanes3 += (unsigned long long)nA; }
 #endif
         // majority vote: this trip runs EITHER the interior-node step OR the leaf step, for the lanes that hold that kind
         // of cursor (the others wait one trip) — so a trip costs one of the two bodies, not their sum.
-        bool interior = active && cur >= 0;
-        int nI = __popcll(wballot(interior));
-        int nL = __popcll(mA) - nI;
-        if (nI >= nL) {
-          if (interior) cur = blas_node_step<COUNT>(S, cur, R, best.t, bl, sp, lc);
-        } else if (active && !interior) {
-          test_leaf<COUNT>(S, cur, o, d, best, best_i, lc);
-          cur = blas_pop(bl, sp);
+        int nI = __popcll(wballot(c >= 0));
+        if (2 * nI >= nA) {
+          if (c >= 0) {
+            if (COUNT) lc.blas_nodes++;
+            const float4* n = (const float4*)((const char*)S.blas_nodes + ((uint32_t)c << 6));
+            float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
+            c = blas_node_eval_flat(q0, q1, q2, q3, R, best.t, bl, sp);
+          }
+        } else if (c < 0 && c != kBlasDone) {
+          test_leaf<COUNT>(S, c, o, d, best, best_i, lc);
+          c = blas_pop(bl, sp);
         }
-        active = mine && cur != kBlasDone;
       }
+      if (mine) cur = c;
       // back to the heap walk (RS:323-325 continues) — or, when nothing of Trace() is left to do (empty object-level stack and
       // no spheres), straight to shading: saves the path one scheduling round trip per bounce
       if (mine && cur == kBlasDone) st = ((cs & 0xff) == 0 && S.n_spheres == 0) ? (best.t < URT_INF ? ST_SHADE : ST_SKY) : ST_RESUME;
@@ -1182,6 +1216,367 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
   }
 #endif
   if (watchdog && (threadIdx.x & 63) == 0) atomicAdd(&ctr->watchdog, 1ull);
+  lc.rays = (threadIdx.x & 63) == 0 ? wave_rays : 0u;
+  flush_counters<COUNT>(lc, ctr);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// mode 5: mode 3 with the triangle-BVH phase turned into a SERVICE shared by the waves of a workgroup.
+// Measured on mode 3 (profiles/README.md, round 2): the kernel is VALU-issue-bound, two thirds of its vector instructions are
+// the triangle-BVH loop, and that loop runs with 24 of 64 lanes on average — a wave owns 64 paths, only those that stand at a
+// mesh can take part, and their number falls while the loop runs.  A VALU instruction costs the same 4 cycles whatever the
+// number of active lanes, so the idle lanes are the cost.
+// Here a path that must enter a triangle BVH does not traverse it on its own lane.  It POSTS the ray: origin/direction to its
+// slot of a per-workgroup mailbox in global memory (L2-resident, written once), the traversal state — closest hit so far, node
+// cursor, stack height — to its slot of a small LDS table, and waits (ST_WAIT).  Any wave of the workgroup that enters the
+// traversal phase CLAIMS waiting rays (of its own paths or of its neighbours') onto its idle lanes — compare-and-swap on the
+// slot's flag word — and keeps claiming while it runs, so the loop stays full for as long as the workgroup has rays waiting:
+// 256 paths feed it instead of 64.  The traversal stack stays where it was: entry e of slot s lives in the LDS column of the
+// path's own lane, whoever walks the ray uses that column.  A finished traversal writes (t, hit, u, v) back to the slot and
+// flags it DONE; the owner picks it up at its next scheduling trip and carries on (RESUME / SHADE / SKY) exactly as in mode 3.
+// A wave that leaves the phase with traversals in flight (other work is waiting) SUSPENDS them: cursor, stack height and the
+// closest hit go back to the slot, which is flagged REQ again — any wave resumes it later.  Foreign state therefore never
+// lives in registers outside the phase.
+// `avail` counts the posted-and-unreserved rays of the workgroup (a semaphore: a wave reserves before it scans, returns what it
+// could not claim), so waves do not all rush for the same few rays.
+// Per-ray arithmetic and operation order are those of modes 0-4 (same device functions): pixels are bit-identical.
+// ---------------------------------------------------------------------------------------------------
+enum : int { ST_WAIT = 6 };
+enum : int { MB_IDLE = 0, MB_REQ = 1, MB_BUSY = 2, MB_DONE = 3 };
+
+__device__ __forceinline__ int lanes_below(unsigned long long m) {      // set bits of m below this lane
+  return (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+}
+__device__ __forceinline__ int lds_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_store(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+#ifndef URT_SERVE_OCC
+#define URT_SERVE_OCC 4
+#endif
+#ifndef URT_SERVE_SLEEP
+#define URT_SERVE_SLEEP 8
+#endif
+// A wave whose live paths are all being walked by its neighbours has nothing to run: it sleeps until one of its rays is
+// answered or a ray is posted that it could walk itself — a short poll loop (one LDS word per lane + the counter), bounded,
+// instead of full scheduling trips.
+__device__ __forceinline__ void serve_wait(bool waiting, const int* my_flag, const int* avail) {
+  for (int spin = 0; spin < 64; spin++) {
+    __builtin_amdgcn_s_sleep(URT_SERVE_SLEEP);
+    bool done = waiting && (lds_load(my_flag) & 3) == MB_DONE;
+    if (wballot(done) != 0 || __builtin_amdgcn_readfirstlane(lds_load(avail)) > 0) break;
+  }
+}
+template <bool COUNT, int BLOCK, int FMODE, bool MULTI>
+__global__ __launch_bounds__(BLOCK, URT_SERVE_OCC) void k_serve(DevScene S, FrameParams P, FrameTable T, float4* __restrict__ result, DevCounters* ctr,
+                                               unsigned int* __restrict__ next, float4* __restrict__ mail) {
+  constexpr int NW = BLOCK / 64;
+  static_assert(NW >= 1 && (NW & (NW - 1)) == 0, "waves per workgroup: a power of two");
+  // LDS of the workgroup: [top of the BVH forest][object-level tables][mailbox: hit x BLOCK float4, best_i, cursor, flag, candidate
+  // list x BLOCK ints, avail][stacks of wave 0][wave 1]...
+  extern __shared__ int lds[];
+  float4* lds4 = (float4*)lds;
+  const float4* top = lds4;
+  for (int i = threadIdx.x; i < P.top_nodes * 4; i += blockDim.x) lds4[i] = S.blas_nodes[i];
+  int at = P.top_nodes * 4;                                     // running offset in float4 units
+  FrontLds L;
+  if (P.lds_mesh) {
+    for (int i = threadIdx.x; i < 2 * S.n_mesh_tlas; i += blockDim.x) lds4[at + i] = S.mesh_tlas[i];
+    L.mesh_tlas = lds4 + at; at += 2 * S.n_mesh_tlas;
+    for (int i = threadIdx.x; i < S.n_meshes; i += blockDim.x) ((int32_t*)(lds4 + at))[i] = S.mesh_root[i];
+    L.mesh_root = (const int32_t*)(lds4 + at); at += (S.n_meshes + 3) / 4;
+    if (P.lds_small) {
+      for (int i = threadIdx.x; i < S.n_meshes; i += blockDim.x) ((int32_t*)(lds4 + at))[i] = S.mesh_small_first[i];
+      L.small_first = (const int32_t*)(lds4 + at); at += (S.n_meshes + 3) / 4;
+      for (int m = threadIdx.x; m < S.n_meshes; m += blockDim.x) {
+        int sf = S.mesh_small_first[m];
+        if (sf >= 0) {
+          uint32_t code = ~(uint32_t)S.mesh_root[m];
+          uint32_t first = code >> 3, cnt = (code & 7u) + 1u;
+          for (uint32_t q = 0; q < 3 * cnt; q++) lds4[at + 3 * sf + q] = S.tri_verts[3 * (size_t)first + q];
+        }
+      }
+      L.small_tris = lds4 + at; at += 3 * S.n_small;
+    }
+  }
+  if (P.lds_sphere) {
+    for (int i = threadIdx.x; i < 2 * S.n_sphere_tlas; i += blockDim.x) lds4[at + i] = S.sphere_tlas[i];
+    L.sphere_tlas = lds4 + at; at += 2 * S.n_sphere_tlas;
+    for (int i = threadIdx.x; i < S.n_spheres; i += blockDim.x) lds4[at + i] = S.sphere_pr[i];
+    L.sphere_pr = lds4 + at; at += S.n_spheres;
+  }
+  float4* m_hit = lds4 + at; at += BLOCK;                       // t, kind|id (int bits; 0 = no hit made in this call yet), u, v
+  int* m_besti = lds + at * 4;                                  // index slot of that hit (the equal-t tie rule), -1 = none
+  int* m_cur = m_besti + BLOCK;                                 // node cursor
+  int* m_flag = m_cur + BLOCK;                                  // MB_* | stack height << 8
+  int* m_cand = m_flag + BLOCK;                                 // per wave: 64 candidate slots of a refill
+  int* m_avail = m_cand + BLOCK;                                // posted rays nobody has reserved yet
+  at += BLOCK + 1;
+  m_flag[threadIdx.x] = MB_IDLE;
+  if (threadIdx.x == 0) *m_avail = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int per_wave = (P.tlas_stack + P.blas_stack) * 64;
+  int* const stacks = lds + at * 4;
+  int* tl = stacks + wave * per_wave + lane;
+  int* bl = tl + P.tlas_stack * 64;
+  const int myslot = (int)threadIdx.x;
+  float4* const wgmail = mail + (size_t)blockIdx.x * (size_t)(2 * BLOCK);
+  LocalCounters lc;
+  const unsigned int tiles_per_frame = (unsigned int)(P.tiles_x * P.n_strips);
+  const unsigned int ntiles = tiles_per_frame * (unsigned int)P.n_frames;
+  WorkCursor wc; wc.shard = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (kWorkShards - 1u);
+  bool exhausted = false;
+  int st = ST_DEAD;
+  // path state
+  int xy = 0;                                    // pixel: x | y << 16
+  int ray_i = 0, kf = 0;                         // kf: bounce index k | frame of the launch << 24
+  float seed = 0;
+  v3 o = mk3(0, 0, 0), d = mk3(0, 0, 1), energy = mk3(0, 0, 0), res = mk3(0, 0, 0), avg = mk3(0, 0, 0);
+  HitRec best; best.t = URT_INF; best.kid = 0; best.u = 0; best.v = 0;
+  int cs = 0;                                    // object-level heap walk: stack height | `tests` flag << 8 (listed FRONT: entries left | next << 8)
+  unsigned int wave_iters = 0, wave_rays = 0;
+  bool watchdog = false;
+  unsigned long long sv[6] = {0, 0, 0, 0, 0, 0};   // COUNT: service visits, trips, lane-trips, claim rounds, rays claimed, rays suspended (per wave)
+
+  for (;;) {
+    if (watchdog) break;
+    // ---- answers to the rays this wave's paths have posted ----
+    if (st == ST_WAIT) {
+      int f = lds_load(m_flag + myslot);
+      if ((f & 3) == MB_DONE) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        float4 h = m_hit[myslot];
+        if (as_int(h.y) != 0) { best.t = h.x; best.kid = as_int(h.y); best.u = h.z; best.v = h.w; }   // a hit made in that call is closer (RS:251)
+        st = ((cs & 0xff) == 0 && S.n_spheres == 0) ? (best.t < URT_INF ? ST_SHADE : ST_SKY) : ST_RESUME;
+      }
+    }
+    unsigned long long mD = wballot(st == ST_DEAD);
+    int nD = __popcll(mD);
+    int nW = __popcll(wballot(st == ST_WAIT));
+    int nS = __popcll(wballot(st == ST_SHADE));
+    int nK = __popcll(wballot(st == ST_SKY));
+    int nF = __popcll(wballot(st == ST_FRONT || st == ST_RESUME));
+    int av = __builtin_amdgcn_readfirstlane(lds_load(m_avail));
+    if (!exhausted && nD > 0 && (nD >= P.refill_min || (nS + nK + nF == 0 && (nW == 0 || av <= 0)))) {
+      int x = 0, y = 0, frame = 0;
+      bool got = wave_fetch_pixels(P, mD, st == ST_DEAD, next, ntiles, wc, exhausted, x, y, tiles_per_frame, &frame);
+      for_each_frame(got, frame, [&](int f, bool mine) {
+        if (mine) {
+          st = ST_FRONT;
+          ray_i = 0; kf = frame << 24; xy = x | (y << 16);
+          avg = mk3(0, 0, 0); res = mk3(0, 0, 0); energy = mk3(1, 1, 1);
+          camera_ray_frame<kTOffAfterParams>(f, P, x, y, true, seed, o, d);
+        }
+      });
+      nF = __popcll(wballot(st == ST_FRONT || st == ST_RESUME));
+      nD = __popcll(wballot(st == ST_DEAD));
+    }
+    bool can_refill = !exhausted && nD >= P.refill_min;
+    if (++wave_iters > kWatchdogIters) { watchdog = true; break; }   // an exit every wave reaches, whatever the data
+    int phase;
+    bool sky_too = false;
+    if (av >= P.blas_min) phase = ST_BLAS;
+    else if (P.shade_split) {
+      if (nS >= P.shade_min) phase = ST_SHADE;
+      else if (nK >= P.sky_min) phase = ST_SKY;
+      else if (nF > 0) phase = ST_FRONT;
+      else if (nS > 0 && nS >= nK) phase = ST_SHADE;
+      else if (nK > 0) phase = ST_SKY;
+      else if (av > 0) phase = ST_BLAS;
+      else if (nW > 0) { serve_wait(st == ST_WAIT, m_flag + myslot, m_avail); continue; }   // every live path of the wave is being walked by a neighbour
+      else if (exhausted) break;
+      else continue;
+    }
+    else if (nS + nK >= P.shade_min) { phase = nS > 0 ? ST_SHADE : ST_SKY; sky_too = true; }
+    else if (nF > 0) phase = ST_FRONT;
+    else if (nS + nK > 0) { phase = nS > 0 ? ST_SHADE : ST_SKY; sky_too = true; }
+    else if (av > 0) phase = ST_BLAS;
+    else if (nW > 0) { serve_wait(st == ST_WAIT, m_flag + myslot, m_avail); continue; }
+    else if (exhausted) break;
+    else continue;
+
+    if (phase == ST_FRONT) {
+      // ---------------- FRONT / RESUME: Trace() up to the next triangle-BVH visit (RS:364-383), as in mode 3 ----------------
+      bool need = false;
+      int32_t cur = kBlasDone; int sp = 0;
+      if (FMODE != 2) wave_rays += (unsigned int)__popcll(wballot(st == ST_FRONT));
+      if (FMODE == 2) {
+        bool mine = st == ST_FRONT || st == ST_RESUME;
+        int r = front_listed<COUNT>(S, P, mine, st == ST_FRONT, o, d, best, cs, tl, cur, lc, L, top, bl, sp, wave_rays);
+        if (mine && r != 2) {
+          if (r == 1) need = true;
+          else st = best.t < URT_INF ? ST_SHADE : ST_SKY;
+        }
+      } else if (st == ST_FRONT || st == ST_RESUME) {
+        int check = cs & 0xff; bool seen = (cs >> 8) != 0;
+        need = FMODE == 1 ? trace_front<COUNT, true, false>(S, st == ST_FRONT, o, d, best, check, seen, tl, 64, cur, lc, L, top, P.top_nodes, bl, &sp)
+                          : trace_front<COUNT, false, false>(S, st == ST_FRONT, o, d, best, check, seen, tl, 64, cur, lc, L);
+        cs = check | (seen ? 256 : 0);
+        if (!need) st = best.t < URT_INF ? ST_SHADE : ST_SKY;
+      }
+      // post the rays that must enter a triangle BVH
+      if (need) {
+        wgmail[2 * myslot] = make_float4(o.x, o.y, o.z, 0.0f);
+        wgmail[2 * myslot + 1] = make_float4(d.x, d.y, d.z, 0.0f);
+        m_hit[myslot] = make_float4(best.t, 0.0f, 0.0f, 0.0f);
+        m_besti[myslot] = -1;
+        m_cur[myslot] = cur;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        lds_store(m_flag + myslot, MB_REQ | (sp << 8));
+        st = ST_WAIT;
+      }
+      int n_post = __popcll(wballot(need));
+      if (n_post > 0 && lane == 0) __hip_atomic_fetch_add(m_avail, n_post, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else if (phase == ST_BLAS) {
+      // ---------------- the traversal service ----------------
+      const bool others = nS + nK + nF > 0 || can_refill;     // own work waits: yield once the loop runs thin
+      bool factive = false;
+      v3 fo = mk3(0, 0, 0), fd = mk3(0, 0, 1);
+      BlasRay R; R.idir = mk3(0, 0, 0); R.nop = mk3(0, 0, 0); R.nom = mk3(0, 0, 0);
+      HitRec fb; fb.t = URT_INF; fb.kid = 0; fb.u = 0; fb.v = 0;
+      int fbest_i = -1, fsp = 0, fhome = 0;
+      int32_t fcur = kBlasDone;
+      int* fstk = bl;
+      int budget = (int)min(P.watchdog_steps, 0x7fffffffu);
+      bool stepped = false;
+      if (COUNT) sv[0]++;
+      for (;;) {
+        unsigned long long mA = wballot(factive);
+        int nA = __popcll(mA);
+        // ---- claim waiting rays onto the idle lanes ----
+        if (64 - nA >= P.pool_inloop) {
+          int a2 = __builtin_amdgcn_readfirstlane(lds_load(m_avail));
+          if (a2 > 0) {
+            int want = 64 - nA, g = 0;
+            if (lane == 0) {
+              int old = __hip_atomic_fetch_add(m_avail, -want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              g = max(0, min(old, want));
+              if (g < want) __hip_atomic_fetch_add(m_avail, want - g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            g = __builtin_amdgcn_readfirstlane(g);
+            if (g > 0) {
+              int total = 0;
+#pragma unroll
+              for (int j = 0; j < NW; j++) {                    // the wave's own paths first, then its neighbours'
+                int s = (((wave + j) & (NW - 1)) << 6) | lane;
+                int f = lds_load(m_flag + s);
+                bool pend = (f & 3) == MB_REQ;
+                unsigned long long m = wballot(pend);
+                int r = total + lanes_below(m);
+                if (pend && r < 64) m_cand[wave * 64 + r] = s | ((f >> 8) << 16);
+                total += __popcll(m);
+              }
+              __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // the list was written by other lanes of this wave
+              int n_take = min(total, g);
+              int r = lanes_below(~mA);
+              bool ok = false; int c = 0;
+              if (!factive && r < n_take) {
+                c = m_cand[wave * 64 + r];
+                int expect = MB_REQ | ((c >> 16) << 8);
+                ok = __hip_atomic_compare_exchange_strong(m_flag + (c & 0xffff), &expect, MB_BUSY, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              }
+              int nc = __popcll(wballot(ok));
+              if (COUNT) { sv[3]++; sv[4] += (unsigned long long)nc; }
+              if (nc < g && lane == 0) __hip_atomic_fetch_add(m_avail, g - nc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              if (ok) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                fhome = c & 0xffff; fsp = c >> 16;
+                float4 qo = wgmail[2 * fhome], qd = wgmail[2 * fhome + 1];
+                float4 h = m_hit[fhome];
+                fo = xyz(qo); fd = xyz(qd);
+                fb.t = h.x; fb.kid = as_int(h.y); fb.u = h.z; fb.v = h.w;
+                fbest_i = m_besti[fhome]; fcur = m_cur[fhome];
+                fstk = stacks + (fhome >> 6) * per_wave + P.tlas_stack * 64 + (fhome & 63);
+                R = blas_ray(fo, fd);
+                factive = true;
+              }
+              mA = wballot(factive);
+              nA = __popcll(mA);
+            }
+          }
+        }
+        // ---- yield? (never before the rays of this visit have advanced one trip: a visit always makes progress) ----
+        if (nA == 0) break;
+        if (stepped && nA < P.blas_exit) {
+          bool mine_done = st == ST_WAIT && (lds_load(m_flag + myslot) & 3) == MB_DONE;
+          if (others || wballot(mine_done) != 0) break;
+        }
+        if (--budget < 0) { watchdog = true; break; }
+        stepped = true;
+        if (COUNT) { sv[1]++; sv[2] += (unsigned long long)nA; }
+        // ---- one trip: EITHER the interior-node step OR the leaf step (majority vote, as in mode 3) ----
+        bool interior = factive && fcur >= 0;
+        int nI = __popcll(wballot(interior));
+        if (nI >= nA - nI) {
+          if (interior) {
+            if (COUNT) lc.blas_nodes++;
+            float4 q0, q1, q2, q3;
+            if (FMODE == 0 && fcur < P.top_nodes) { const float4* n = top + 4 * fcur; q0 = n[0]; q1 = n[1]; q2 = n[2]; q3 = n[3]; }
+            else { const float4* n = (const float4*)((const char*)S.blas_nodes + ((uint32_t)fcur << 6)); q0 = n[0]; q1 = n[1]; q2 = n[2]; q3 = n[3]; }
+            fcur = blas_node_eval(q0, q1, q2, q3, R, fb.t, fstk, fsp);
+          }
+        } else if (factive && !interior) {
+          test_leaf<COUNT>(S, fcur, fo, fd, fb, fbest_i, lc);
+          fcur = blas_pop(fstk, fsp);
+        }
+        // ---- finished traversals: answer and free the lane ----
+        if (factive && fcur == kBlasDone) {
+          m_hit[fhome] = make_float4(fb.t, as_float(fb.kid), fb.u, fb.v);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          lds_store(m_flag + fhome, MB_DONE);
+          factive = false;
+        }
+      }
+      // ---- suspend what is still in flight: any wave resumes it ----
+      if (factive) {
+        m_hit[fhome] = make_float4(fb.t, as_float(fb.kid), fb.u, fb.v);
+        m_besti[fhome] = fbest_i;
+        m_cur[fhome] = fcur;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        lds_store(m_flag + fhome, MB_REQ | (fsp << 8));
+      }
+      int n_back = __popcll(wballot(factive));
+      if (COUNT) sv[5] += (unsigned long long)n_back;
+      if (n_back > 0 && lane == 0) __hip_atomic_fetch_add(m_avail, n_back, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+      // ---------------- SHADE + bookkeeping of CSMain's loops (RS:444-468), as in mode 3 ----------------
+      bool next_ray = false;
+      bool cont = false, shaded = false;
+      if (phase == ST_SHADE) {
+        if (st == ST_SHADE) { shaded = true; cont = shade_surface<COUNT>(S, best, o, d, energy, res, seed, (float)(xy & 0xffff), (float)((unsigned)xy >> 16), lc); }
+      }
+      if (phase == ST_SKY || (sky_too && nK > 0)) {
+        if (st == ST_SKY) { shaded = true; cont = shade_sky<COUNT>(S, d, energy, res, lc); }
+      }
+      if (shaded) {
+        kf++;
+        st = ST_FRONT;
+        if (!cont || (kf & 0xffffff) >= P.num_bounces) {    // RS:453,457-460
+          v3 sum = (MULTI ? avg : mk3(0, 0, 0)) + res;       // RS:464
+          if (MULTI) { avg = sum; ray_i++; next_ray = ray_i < P.num_rays; }
+          if (!next_ray) {
+            float n = (float)P.num_rays;
+            st_result(result + (size_t)((unsigned)kf >> 24) * P.frame_stride + (size_t)((unsigned)xy >> 16) * P.width + (xy & 0xffff),
+                      make_float4(sum.x / n, sum.y / n, sum.z / n, 1.0f));   // RS:468
+            st = ST_DEAD;
+          }
+        }
+      }
+      if (MULTI) {                                          // RS:444: next ray of the pixel, _Seed carries over
+        for_each_frame(next_ray, (int)((unsigned)kf >> 24), [&](int f, bool mine) {
+          if (mine) {
+            res = mk3(0, 0, 0); energy = mk3(1, 1, 1); kf &= (int)0xff000000;
+            camera_ray_frame<kTOffAfterParams>(f, P, xy & 0xffff, (int)((unsigned)xy >> 16), false, seed, o, d);
+          }
+        });
+      }
+    }
+  }
+  if (watchdog && (threadIdx.x & 63) == 0) atomicAdd(&ctr->watchdog, 1ull);
+  if (COUNT && (threadIdx.x & 63) == 0) {
+    DevCounters* c = ctr + (blockIdx.x & (kCounterShards - 1));
+    for (int q = 0; q < 6; q++) if (sv[q]) atomicAdd(&c->serve[q], sv[q]);
+  }
   lc.rays = (threadIdx.x & 63) == 0 ? wave_rays : 0u;
   flush_counters<COUNT>(lc, ctr);
 }
@@ -1679,6 +2074,7 @@ size_t sched_lds_bytes(const DevScene& S, const FrameParams& P) {
   if (P.lds_mesh) f4 += 2 * (size_t)S.n_mesh_tlas + ((size_t)S.n_meshes + 3) / 4;
   if (P.lds_small) f4 += ((size_t)S.n_meshes + 3) / 4 + 3 * (size_t)S.n_small;
   if (P.lds_sphere) f4 += 2 * (size_t)S.n_sphere_tlas + (size_t)S.n_spheres;
+  if (P.serve) f4 += 2 * (size_t)P.block_threads + 1;          // mode 5: the workgroup's mailbox (k_serve)
   return f4 * 16 + (size_t)(P.tlas_stack + P.blas_stack) * 64 * (size_t)(P.block_threads / 64) * sizeof(int);
 }
 
@@ -1722,6 +2118,46 @@ hipError_t launch_sched(const DevScene& S, const FrameParams& P, const FrameTabl
                                           : launch_sched_b<false, 64>(S, P, T, result, ctr, next, n_blocks, lds, front_mode, st);
   return count ? launch_sched_b<true, 256>(S, P, T, result, ctr, next, n_blocks, lds, front_mode, st)
                : launch_sched_b<false, 256>(S, P, T, result, ctr, next, n_blocks, lds, front_mode, st);
+}
+
+template <bool COUNT, int FMODE, bool MULTI>
+static hipError_t launch_serve_t(const DevScene& S, const FrameParams& P, const FrameTable& T, float4* result, DevCounters* ctr,
+                                 unsigned int* next, float4* mail, int n_blocks, size_t lds, hipStream_t st) {
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_serve<COUNT, 256, FMODE, MULTI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL((k_serve<COUNT, 256, FMODE, MULTI>), dim3(n_blocks), dim3(256), lds, st, S, P, T, result, ctr, next, mail);
+  return hipGetLastError();
+}
+
+template <bool COUNT, int FMODE>
+static hipError_t launch_serve_m(const DevScene& S, const FrameParams& P, const FrameTable& T, float4* result, DevCounters* ctr,
+                                 unsigned int* next, float4* mail, int n_blocks, size_t lds, hipStream_t st) {
+  return P.num_rays > 1 ? launch_serve_t<COUNT, FMODE, true>(S, P, T, result, ctr, next, mail, n_blocks, lds, st)
+                        : launch_serve_t<COUNT, FMODE, false>(S, P, T, result, ctr, next, mail, n_blocks, lds, st);
+}
+
+template <bool COUNT>
+static hipError_t launch_serve_b(const DevScene& S, const FrameParams& P, const FrameTable& T, float4* result, DevCounters* ctr,
+                                 unsigned int* next, float4* mail, int n_blocks, size_t lds, int front_mode, hipStream_t st) {
+  if (front_mode == 2) return launch_serve_m<COUNT, 2>(S, P, T, result, ctr, next, mail, n_blocks, lds, st);
+  if (front_mode == 1) return launch_serve_m<COUNT, 1>(S, P, T, result, ctr, next, mail, n_blocks, lds, st);
+  return launch_serve_m<COUNT, 0>(S, P, T, result, ctr, next, mail, n_blocks, lds, st);
+}
+
+hipError_t launch_serve(const DevScene& S, const FrameParams& P, const FrameTable& T, float4* result, DevCounters* ctr,
+                        unsigned int* next, float4* mail, int n_blocks, int front_mode, bool count, hipStream_t st) {
+  if (n_blocks <= 0) return hipSuccess;
+  if (P.block_threads != 256 || !P.serve || !mail) return hipErrorInvalidValue;
+  if (P.n_frames < 1 || P.n_frames > kMaxFramesPerLaunch) return hipErrorInvalidValue;
+  if (front_mode == 2 && (!P.lds_mesh || S.n_meshes > 12 || P.tlas_stack < 2)) return hipErrorInvalidValue;
+  hipError_t e = hipMemsetAsync(next, 0, kWorkShards * 32 * sizeof(unsigned int), st);
+  if (e != hipSuccess) return e;
+  size_t lds = sched_lds_bytes(S, P);
+  if (P.top_nodes <= 0 && front_mode == 1) front_mode = 0;
+  return count ? launch_serve_b<true>(S, P, T, result, ctr, next, mail, n_blocks, lds, front_mode, st)
+               : launch_serve_b<false>(S, P, T, result, ctr, next, mail, n_blocks, lds, front_mode, st);
 }
 
 size_t pool_lds_bytes(const FrameParams& P, int k) {

@@ -67,7 +67,8 @@ struct FrameParams {
   int top_nodes;            // mode 3: triangle-BVH nodes [0, top_nodes) are copied to LDS (breadth-first top of the forest); 0 = none
   int lds_small;            // mode 3: triangle records of the single-leaf MeshObjects in LDS (needs lds_mesh) (0/1)
   int lds_mesh, lds_sphere; // mode 3: keep the object-level mesh heap + roots / sphere heap + spheres in LDS (0/1)
-  int pool_inloop;          // mode 4: idle lanes that trigger a re-feed of the traversal phase from the waiting rays (1..64)
+  int serve;                // mode 5: the traversal phase is a service shared by the waves of a workgroup (kernels.hip k_serve) (0/1)
+  int pool_inloop;          // modes 4, 5: idle lanes that trigger a re-feed of the traversal phase from the waiting rays (1..64)
   int pool_other_min;       // mode 4: lanes of FRONT / SHADE work that make those phases worth a trip while rays queue for the BVH
   unsigned int watchdog_steps;  // cap on traversal trips per scheduled BLAS phase: a few times (nodes + leaves) of the scene
   // mode 3, frame batching: ONE launch traces n_frames consecutive frames of the same scene/resolution (the library defers
@@ -95,7 +96,11 @@ struct alignas(128) DevCounters {            // one shard = one 128-byte line of
   unsigned long long rays, tlas_nodes, blas_nodes, tri_tests, sphere_tests;
   unsigned long long hit_tri, hit_sphere, hit_ground, hit_sky;
   unsigned long long watchdog;   // waves that left a persistent kernel through its iteration cap (must stay 0)
+  // mode 5 with count_stats: visits of the traversal service, its trips, active lanes summed over the trips, claim rounds,
+  // rays claimed, rays suspended (urt_debug_serve_stats)
+  unsigned long long serve[6];
 };
+static_assert(sizeof(DevCounters) == 128, "one counter shard = one 128-byte line");
 
 // path state of the wavefront pipeline: 4 x float4 per path, SoA by record
 //   s0 = origin.xyz, seed   s1 = direction.xyz, pixel (int bits: y << 16 | x)

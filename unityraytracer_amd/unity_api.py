@@ -74,6 +74,13 @@ class Context:
     def reset_counters(self):
         self.check(self.lib.urt_reset_counters(self._h))
 
+    def serve_stats(self) -> dict:
+        """kernel_mode 5 with count_stats: the shared traversal service since the last reset_counters()."""
+        a = (C.c_ulonglong * 6)()
+        self.check(self.lib.urt_debug_serve_stats(self._h, a))
+        k = ("visits", "trips", "lane_trips", "claim_rounds", "claimed", "suspended")
+        return dict(zip(k, [int(x) for x in a]))
+
     def scene_info(self) -> dict:
         """Sizes of the current device scene's triangle BVH and the host time its preparation took (prepares it if stale)."""
         nn, nt, md, ms = C.c_int(), C.c_int(), C.c_int(), C.c_float()
