@@ -160,14 +160,17 @@ typedef struct urt_counters {
 /* Options: "blas_builder" (0 = binned-SAH triangle BVH built on host threads, the default: best trees; 1 = LBVH built on the GPU
  *                          from the uploaded buffers — Morton sort + Karras hierarchy, csrc/lbvh.hip: milliseconds instead of tens
  *                          of milliseconds for scenes whose objects move; same pixels),
- *          "frames_per_launch" (0 = auto: own stream -> 16 frames per launch (fewer if 16 Result slots exceed 8 GiB), caller's stream -> 1;
- *                               1 = every dispatch is its own launch; 2..16 = batch that many, also on a caller's stream),
+ *          "frames_per_launch" (0 = auto: own stream -> up to 64 frames per launch (fewer if their Result slots exceed 8 GiB), caller's stream -> 1;
+ *                               1 = every dispatch is its own launch; 2..64 = batch that many, also on a caller's stream),
  *          "count_stats" (0/1: per-dispatch traversal counters, slower build of the kernel),
  *          "time_dispatch" (0/1: bracket each dispatch with HIP events, read by urt_get_counters),
  *          "kernel_mode" (0 = one thread per pixel; 1 = one launch per bounce over compacted path queues;
  *                         2 = persistent waves with in-wave path regeneration;
  *                         3 = 2 + lanes scheduled by phase inside the wave, the default;
- *                         4 = 3 with a pool of 64 x pool_k paths per wave kept in LDS, experimental),
+ *                         4 = 3 with a pool of 64 x pool_k paths per wave kept in LDS, experimental;
+ *                         5 = 3 with the triangle-BVH phase as a service shared by the four waves of a workgroup (rays are
+ *                             posted to a mailbox, any wave claims and walks them; "serve_refill" 1..64, "blas_min" up to 256):
+ *                             measured alternative, slower than 3),
  *          "block_threads" (64 | 128 | 256: modes 0-2), "xcd_run" (>= 1: run length of the tile order),
  *          "tile_order" (0 bottom-up | 1 top-down), "waves_per_cu" (0 = auto, 1..32), "refill_min" (1..64),
  *          mode 3: "blas_min" / "blas_exit" / "shade_min" / "sky_min" (1..64: vote thresholds), "shade_split" (-1 auto | 0 | 1: surface hits and

@@ -259,8 +259,20 @@ URT_HD float blas_rcp(float d) {
 // ---------------------------------------------------------------------------------------------
 // rand()  (RS:77-81, A.1).  State: pixel (float2 of absolute pixel coordinates) + running seed.
 // ---------------------------------------------------------------------------------------------
+// x / c for a CONSTANT c whose correctly rounded reciprocal is y, without the divider: q = RN(x y), r = x - q c (exact, one
+// fma), q' = RN(q + r y) (Markstein's correction step).  tests/test_oracle_math.py checks q' against the IEEE quotient for
+// EVERY finite float x, for the two constants used below: c = 17 agrees everywhere, c = 100 everywhere above 4.8e-38; zeros (sign), the
+// bottom of the range, infinities and NaN take the divider.  Ten instructions fewer per division on the GPU, same value.
+URT_HD float f_div_const(float x, float c, float y) {
+  float ax = f_abs(x);
+  if (!(ax >= 1e-30f && ax <= 3.0e38f)) return x / c;
+  float q = x * y;
+  float r = f_fma(-q, c, x);
+  return f_fma(r, y, q);
+}
+
 URT_HD float rand_next(float& seed, float px, float py) {
-  float a = (seed + seed / 17.0f) / 100.0f;
+  float a = f_div_const(seed + f_div_const(seed, 17.0f, 1.0f / 17.0f), 100.0f, 1.0f / 100.0f);   // (seed + seed / 17) / 100, RS:78
   float d = dot2(px, py, 12.9898f, 78.233f);
   float r = f_frac(f_sin(a * d) * 43758.5453f);
   seed = seed + 0.5f;

@@ -551,6 +551,30 @@ void oracle_math_probe(int fn, const float* a, const float* b, const float* c, f
   }
 }
 
+// Exhaustive check of urt::f_div_const (include/urt_math.h) against the IEEE quotient: every float bit pattern x (both signs,
+// zeros, denormals, infinities, NaNs) for the constant c.  Returns the number of x whose results differ in any bit.
+unsigned long long oracle_check_div_const(float c, int n_threads) {
+  if (n_threads < 1) n_threads = 1;
+  const float y = 1.0f / c;
+  std::vector<unsigned long long> bad((size_t)n_threads, 0ull);
+  auto work = [&](int tid) {
+    unsigned long long nb = 0;
+    for (uint64_t u = (uint64_t)tid; u <= 0xffffffffull; u += (uint64_t)n_threads) {
+      float x = bits_f((uint32_t)u);
+      float got = f_div_const(x, c, y), want = x / c;
+      bool same = f_bits(got) == f_bits(want) || (got != got && want != want);   // any NaN for a NaN
+      nb += same ? 0 : 1;
+    }
+    bad[(size_t)tid] = nb;
+  };
+  std::vector<std::thread> th;
+  for (int t = 0; t < n_threads; t++) th.emplace_back(work, t);
+  for (auto& t : th) t.join();
+  unsigned long long total = 0;
+  for (auto b : bad) total += b;
+  return total;
+}
+
 // Geometry probes: each evaluates ONE reference function on explicit inputs.
 // ray = origin(3) direction(3); returns 1 on hit and writes t,u,v.
 int oracle_probe_triangle(const float* ray6, const float* v0, const float* v1, const float* v2, float* tuv) {

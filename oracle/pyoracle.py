@@ -61,6 +61,8 @@ def load(build: bool = True):
     lib.oracle_accumulate.restype = None
     lib.oracle_math_probe.argtypes = [i, vp, vp, vp, vp, i]
     lib.oracle_math_probe.restype = None
+    lib.oracle_check_div_const.argtypes = [C.c_float, i]
+    lib.oracle_check_div_const.restype = C.c_ulonglong
     lib.oracle_probe_triangle.argtypes = [vp, vp, vp, vp, vp]
     lib.oracle_probe_triangle.restype = i
     lib.oracle_probe_aabb.argtypes = [vp, vp]
@@ -188,6 +190,11 @@ def math_probe(fn: str, a, b=None, c=None) -> np.ndarray:
     out = np.zeros_like(a)
     lib.oracle_math_probe(ids[fn], _ptr(a), _ptr(b), _ptr(c), _ptr(out), a.size)
     return out
+
+
+def check_div_const(c: float, threads: int = 8) -> int:
+    """Bit patterns x (all 2^32) for which urt::f_div_const(x, c, 1/c) differs from the IEEE quotient x / c."""
+    return int(load().oracle_check_div_const(float(c), int(threads)))
 
 
 def probe_triangle(origin, direction, v0, v1, v2):

@@ -31,6 +31,14 @@ if stats:
         if KERNEL in r["Name"]:
             kname, avg_ns, calls = r["Name"], float(r["AverageNs"]), int(r["Calls"])
             print("kernel stats:", r["Name"][:70], "calls", r["Calls"], "avg ns", r["AverageNs"])
+    # duration of the timed launch itself (the last one of the kernel) from the kernel trace next to the stats
+    last_ns = None
+    for tf in glob.glob(stats[0].replace("kernel_stats.csv", "kernel_trace.csv")):      # the trace of the same run (same pid prefix)
+        rows = [r for r in csv.DictReader(open(tf)) if KERNEL in r["Kernel_Name"]]
+        if rows:
+            r = max(rows, key=lambda r: int(r["Start_Timestamp"]))
+            last_ns = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+            print("timed launch (last of", len(rows), "):", last_ns, "ns")
 pmc = {}
 for f in newest(os.path.join(src, "pmc_*", "**", "*counter_collection.csv")):
     acc = {}
@@ -38,7 +46,9 @@ for f in newest(os.path.join(src, "pmc_*", "**", "*counter_collection.csv")):
         if KERNEL not in r["Kernel_Name"]: continue
         acc.setdefault(r["Counter_Name"], {}).setdefault(r["Dispatch_Id"], 0.0)
         acc[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
-    for k, per in acc.items(): pmc[k] = sum(per.values()) / len(per)      # average per LAUNCH
+    # the TIMED launch = the last launch of the kernel in the run (the earlier one traces the warm-up frames); sums over the
+    # counter's instances (XCDs / SEs) of that one dispatch
+    for k, per in acc.items(): pmc[k] = per[max(per, key=int)]
 json.dump(pmc, open(os.path.join(dst, f"{prefix}_pmc_k_sched.json"), "w"), indent=1, sort_keys=True)
 print(json.dumps(pmc, indent=1, sort_keys=True))
 if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
@@ -52,8 +62,9 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
         "kernel": kname, "round": rnd, "frames_per_launch": rl.get("frames_per_launch"),
         "FETCH_SIZE_KB_per_launch": pmc["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": pmc["WRITE_SIZE"],
         "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request -> doubled (MI355X_MICROARCH.md 'HBM'); WRITE_SIZE exact",
-        "hbm_bytes_per_launch": hbm, "rocprof_avg_launch_ms": None if avg_ns is None else avg_ns / 1e6, "rocprof_launches": calls,
+        "hbm_bytes_per_launch": hbm, "rocprof_timed_launch_ms": None if not stats or last_ns is None else last_ns / 1e6,
+        "rocprof_avg_launch_ms": None if avg_ns is None else avg_ns / 1e6, "rocprof_launches": calls,
         "bench_launch_ms": rl.get("launch_ms"), "algorithmic_bytes_per_launch": rl.get("algorithmic_bytes_per_launch"), "frac": rl.get("frac"),
-        "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --config {cfg} --steps 20 --warmup 5 --no-cpu-baseline; averages over the launches of the run"}
+        "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --config {cfg} --steps 20 --warmup 5 --no-cpu-baseline; the TIMED launch of the run (its last launch of the kernel; the earlier one traces the warm-up frames)"}
     json.dump(allcfg, open(path, "w"), indent=1)
     print("hbm bytes per launch", hbm)

@@ -61,6 +61,22 @@ def test_batched_frames_equal_single_launches_and_oracle(gpu_ctx, scene_name):
     assert bits_equal(ref_conv, acc)
 
 
+def test_long_batches_up_to_64_frames_per_launch(gpu_ctx):
+    """The frame table of a launch lives in device memory (staged through pinned host slots, four launches deep): up to 64
+    frames share one launch.  70 frames as 64 + 6 (auto), 40 + 30 and 7 x 10 — more launches than staging slots — equal 70
+    single launches bit for bit."""
+    sc = scenes.mixed_test_scene(96, 56)
+    n = 70
+    ref_conv, ref_last, _, c1 = run_frames(gpu_ctx, sc, n, 1, peek_at=())
+    assert c1["launches"] == n
+    for fpl, launches in ((0, 2), (64, 2), (40, 2), (10, 7)):
+        conv, last, _, c = run_frames(gpu_ctx, sc, n, fpl, peek_at=())
+        assert bits_equal(conv, ref_conv) and bits_equal(last, ref_last), fpl
+        assert c["launches"] == launches and c["dispatches"] == n and c["rays"] == c1["rays"] and c["watchdog_trips"] == 0, (fpl, c)
+    with pytest.raises(Exception):
+        gpu_ctx.set_option("frames_per_launch", 65)
+
+
 def test_batch_of_strips_equals_full_frames(gpu_ctx):
     """Multi-GPU strips (partial-coverage dispatches) are batched too: the pixels outside a rank's strips stay the zeros of
     the freshly created RenderTexture in every renamed slot."""

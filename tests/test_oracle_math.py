@@ -87,3 +87,19 @@ def test_rand_structure():
     wrap = np.minimum(np.abs(r - ref), 1.0 - np.abs(r - ref))
     assert (wrap < 0.0079).mean() > 0.99        # within 2 quanta (2^-7) of the independent evaluation almost always
     assert (wrap == 0).mean() > 0.80            # and mostly identical
+
+
+def test_division_by_the_rand_constants_is_the_ieee_quotient_for_every_float():
+    """rand() divides by 17 and by 100 (RS:78).  include/urt_math.h evaluates both as a reciprocal multiplication plus one
+    fma correction step (f_div_const; the divider only for zeros, the bottom of the range, infinities and NaN) — ten GPU
+    instructions fewer per division.  EXHAUSTIVE: all 2^32 bit patterns of x give the bits of x / c, for both constants."""
+    assert pyoracle.check_div_const(17.0, threads=8) == 0
+    assert pyoracle.check_div_const(100.0, threads=8) == 0
+    # the golden values of rand() itself are unchanged: the same formula with true divisions, evaluated in numpy float32
+    seed = np.float32([0.5, 1.0, 7.25, 63.5, 1e-3])
+    a = ((seed + seed / np.float32(17)) / np.float32(100)).astype(np.float32)
+    px, py = np.float32([3, 100, 1919, 7, 640]), np.float32([5, 200, 1079, 0, 360])
+    d = (py.astype(np.float64) * np.float64(np.float32(78.233)) + np.float64(np.float32(px.astype(np.float64) * np.float64(np.float32(12.9898))))).astype(np.float32)
+    s_ = pyoracle.math_probe("sin", (a * d).astype(np.float32))
+    v = (s_ * np.float32(43758.5453)).astype(np.float32)
+    assert np.array_equal(pyoracle.math_probe("rand", seed, px, py), (v - np.floor(v)).astype(np.float32))

@@ -96,6 +96,12 @@ struct urt_context {
   DevCounters* d_counters = nullptr;        // kCounterShards shards
   unsigned int* d_next = nullptr;           // persistent mode: frame work counter
   float4* d_mail = nullptr; size_t mail_slots = 0;   // kernel_mode 5: posted rays (2 float4 per thread of the resident grid)
+  // frame tables of the batched launches: kTableSlots pinned host images + device copies, used round-robin; a slot is reused
+  // once the copy of its previous use has left the host image (event)
+  static constexpr int kTableSlots = 4;
+  FrameUniforms* h_tables = nullptr; FrameUniforms* d_tables = nullptr;
+  hipEvent_t table_ev[kTableSlots] = {nullptr, nullptr, nullptr, nullptr};
+  unsigned int table_next = 0;
   uint64_t pixels_dispatched = 0;
   int n_cus = 256;
 
@@ -129,7 +135,7 @@ struct urt_context {
   float last_prepare_ms = 0;                // host wall time of the last scene preparation (buffers -> device scene)
   int n_scene_tris = 0;                     // triangles of the prepared scene
   int scene_max_depth = 0;
-  int opt_frames_per_launch = 0;            // 0 = auto (own stream: 16 frames per launch, fewer when 16 Result slots would exceed 8 GiB; caller's stream: 1), 1 = off, 2..16
+  int opt_frames_per_launch = 0;            // 0 = auto (own stream: 64 frames per launch, fewer when the Result slots would exceed 8 GiB; caller's stream: 1), 1 = off, 2..64
   uint64_t scene_epoch = 0;                 // bumps at every scene preparation
   struct PostOp { int kind; int frame; urt_handle tex; urt_handle dst; float sample; int first_row, row_stride; void* dense; };   // kind 0 = blit_add(tex@frame -> dst), 1 = pack_rows(tex -> dense)
   struct Pending {
@@ -371,6 +377,7 @@ int prepare_scene(urt_context* ctx) {
     return fail(ctx, URT_ERR_SCENE, "object-level BVH deeper than the reference's 32-entry traversal stack (RS:73-74)");
   ctx->tlas_stack = std::max(2, lv + 1);
   if (n_blas_nodes >= (1u << 26)) return fail(ctx, URT_ERR_SCENE, "triangle BVH larger than 2^26 nodes (4 GiB)");   // kernels address nodes by 32-bit byte offsets
+  if ((uint64_t)n_tris * 48ull >= (1ull << 32)) return fail(ctx, URT_ERR_SCENE, "more than 2^32 / 48 triangles (4 GiB of triangle records)");   // 32-bit byte offsets as well
   ctx->blas_stack = std::max(2, blas_max_depth + 1);
   ctx->n_blas_nodes = (int)std::min<size_t>(0x7fffffff, n_blas_nodes);
   ctx->n_scene_tris = (int)n_tris; ctx->scene_max_depth = blas_max_depth;
@@ -493,8 +500,23 @@ int configure_sched(urt_context* ctx, const DevScene& S, FrameParams& P, bool to
 }
 
 // Launch the phase-scheduled trace kernel for P.n_frames frames (uniforms T) into result + f * P.frame_stride.
+static constexpr int kAutoFrames = 64;     // frames per launch when "frames_per_launch" is 0 (auto) on the library's own stream
+
 int launch_sched_frames(urt_context* ctx, const DevScene& S, const FrameParams& P, const FrameTable& T, float4* result,
                         int front_mode, bool count) {
+  // the launch's frame table -> device memory, in stream order (pinned staging slot: the copy does not wait for the stream)
+  if (!ctx->h_tables) {
+    URT_HIP(ctx, hipHostMalloc((void**)&ctx->h_tables, sizeof(FrameUniforms) * kMaxFramesPerLaunch * urt_context::kTableSlots, hipHostMallocDefault));
+    URT_HIP(ctx, hipMalloc((void**)&ctx->d_tables, sizeof(FrameUniforms) * kMaxFramesPerLaunch * urt_context::kTableSlots));
+    for (int k = 0; k < urt_context::kTableSlots; k++) URT_HIP(ctx, hipEventCreateWithFlags(&ctx->table_ev[k], hipEventDisableTiming));
+  }
+  const unsigned int slot = ctx->table_next++ % (unsigned int)urt_context::kTableSlots;
+  if (ctx->table_next > (unsigned int)urt_context::kTableSlots) URT_HIP(ctx, hipEventSynchronize(ctx->table_ev[slot]));   // (four launches ago: long done)
+  FrameUniforms* h_slot = ctx->h_tables + (size_t)slot * kMaxFramesPerLaunch;
+  FrameUniforms* d_table = ctx->d_tables + (size_t)slot * kMaxFramesPerLaunch;
+  std::memcpy(h_slot, T.f, sizeof(FrameUniforms) * (size_t)P.n_frames);
+  URT_HIP(ctx, hipMemcpyAsync(d_table, h_slot, sizeof(FrameUniforms) * (size_t)P.n_frames, hipMemcpyHostToDevice, ctx->stream));
+  URT_HIP(ctx, hipEventRecord(ctx->table_ev[slot], ctx->stream));
   int waves_per_block = P.block_threads / 64;
   long want = ((long)P.tiles_x * P.n_strips * P.n_frames + waves_per_block - 1) / waves_per_block;
   // resident waves per CU: every slot the registers allow (k_sched: 96 VGPRs -> 5 waves/SIMD = 20 per CU).  While the
@@ -518,8 +540,8 @@ int launch_sched_frames(urt_context* ctx, const DevScene& S, const FrameParams& 
     rc = take_event(ctx, &e1); if (rc) return rc;
     URT_HIP(ctx, hipEventRecord(e0, ctx->stream));
   }
-  hipError_t le = P.serve ? launch_serve(S, P, T, result, ctx->d_counters, ctx->d_next, ctx->d_mail, nb, front_mode, count, ctx->stream)
-                          : launch_sched(S, P, T, result, ctx->d_counters, ctx->d_next, nb, front_mode, count, ctx->stream);
+  hipError_t le = P.serve ? launch_serve(S, P, d_table, result, ctx->d_counters, ctx->d_next, ctx->d_mail, nb, front_mode, count, ctx->stream)
+                          : launch_sched(S, P, d_table, result, ctx->d_counters, ctx->d_next, nb, front_mode, count, ctx->stream);
   if (ctx->opt_time_dispatch) {
     (void)hipEventRecord(e1, ctx->stream);
     ctx->timing.emplace_back(e0, e1);
@@ -580,11 +602,14 @@ int batch_limit(urt_context* ctx, const FrameParams& P) {
   int lim = ctx->opt_frames_per_launch;
   if (lim == 0) {
     if (ctx->stream != ctx->own_stream) return 1;        // a caller that shares its stream expects the work ON the stream when dispatch returns
-    // as many frames as the kernel-argument table holds (16), within 8 GiB of Result slots: 2160p still gains 3-8 % from 16
-    // frames per launch over 5 (profiles/r02_logs/r2_fpl4k.log), and 16 x 133 MB is nothing on a 288 GB part
+    // kAutoFrames frames per launch, within 8 GiB of Result slots: 2160p still gains from long launches (profiles/r02_logs/r2_fpl4k.log),
+    // and 32 x 133 MB is nothing on a 288 GB part
     uint64_t frame_bytes = (uint64_t)P.width * (uint64_t)P.height * sizeof(float4);
-    lim = (int)std::min<uint64_t>(kMaxFramesPerLaunch, std::max<uint64_t>(1, (8ull << 30) / std::max<uint64_t>(1, frame_bytes)));
+    lim = (int)std::min<uint64_t>(kAutoFrames, std::max<uint64_t>(1, (8ull << 30) / std::max<uint64_t>(1, frame_bytes)));
   }
+  // the work counter hands out 32-bit pixel slots: frames x tiles x 64 must stay below 2^32
+  uint64_t slots = std::max<uint64_t>(1, (uint64_t)P.tiles_x * (uint64_t)P.n_strips * 64u);
+  lim = (int)std::min<uint64_t>((uint64_t)lim, std::max<uint64_t>(1, 0xfffffffeull / slots));
   return std::max(1, std::min(lim, (int)kMaxFramesPerLaunch));
 }
 
@@ -635,7 +660,7 @@ int do_dispatch(urt_context* ctx, int kernel, int gx, int gy, int gz, int first_
   P.blas_exit = ctx->opt_blas_exit > 0 ? ctx->opt_blas_exit : (S.n_meshes > 1 ? 9 : 14); P.shade_min = ctx->opt_shade_min; P.sky_min = ctx->opt_sky_min;
   P.n_frames = 1; P.frame_stride = 0;
   if (P.n_strips == 0 || P.tiles_x == 0) return URT_OK;
-  if ((uint64_t)P.tiles_x * (uint64_t)P.n_strips * 64u * (uint64_t)kMaxFramesPerLaunch >= 0xffffffffull)
+  if ((uint64_t)P.tiles_x * (uint64_t)P.n_strips * 64u >= 0xffffffffull)
     return fail(ctx, URT_ERR_INVALID_ARGUMENT, "Dispatch: too many pixel slots in one dispatch");
 
   // region pixels this dispatch writes (threads outside Result write nothing, RS:468)
@@ -802,6 +827,9 @@ int urt_context_destroy(urt_context* ctx) {
   if (ctx->d_counters) (void)hipFree(ctx->d_counters);
   if (ctx->d_next) (void)hipFree(ctx->d_next);
   if (ctx->d_mail) (void)hipFree(ctx->d_mail);
+  if (ctx->d_tables) (void)hipFree(ctx->d_tables);
+  if (ctx->h_tables) (void)hipHostFree(ctx->h_tables);
+  for (hipEvent_t e : ctx->table_ev) if (e) (void)hipEventDestroy(e);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
   return URT_OK;
@@ -1148,7 +1176,7 @@ int urt_set_option(urt_context* ctx, const char* name, int value) {
     if (value != ctx->opt_blas_builder) ctx->scene_dirty = true;
     ctx->opt_blas_builder = value;
   } else if (std::strcmp(name, "frames_per_launch") == 0) {
-    if (value < 0 || value > kMaxFramesPerLaunch) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "frames_per_launch must be in [0, 16] (0 = auto)");
+    if (value < 0 || value > kMaxFramesPerLaunch) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "frames_per_launch must be in [0, 64] (0 = auto)");
     ctx->opt_frames_per_launch = value;
   } else if (std::strcmp(name, "count_stats") == 0) ctx->opt_count_stats = value ? 1 : 0;
   else if (std::strcmp(name, "time_dispatch") == 0) ctx->opt_time_dispatch = value ? 1 : 0;

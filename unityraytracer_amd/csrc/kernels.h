@@ -14,14 +14,14 @@ hipError_t launch_wavefront(const DevScene& S, const FrameParams& P, const PathQ
 hipError_t launch_persist(const DevScene& S, const FrameParams& P, float4* result, DevCounters* ctr, unsigned int* next,
                           int n_blocks, bool count, hipStream_t st);
 // mode 3: persistent waves whose lanes are scheduled by phase (FRONT / BLAS / SHADE) inside the wave
-// One launch traces P.n_frames consecutive frames (uniforms in T, Result images P.frame_stride apart from `result`).
+// One launch traces P.n_frames consecutive frames (uniforms: T[0 .. n_frames) in DEVICE memory, Result images P.frame_stride apart from `result`).
 // front_mode: 0 = rays enter a triangle BVH through the BLAS phase only, 1 = they first walk its LDS-resident top inside FRONT,
 // 2 = listed form of 1 (needs P.lds_mesh and n_meshes <= 12)
-hipError_t launch_sched(const DevScene& S, const FrameParams& P, const FrameTable& T, float4* result, DevCounters* ctr,
+hipError_t launch_sched(const DevScene& S, const FrameParams& P, const FrameUniforms* T, float4* result, DevCounters* ctr,
                         unsigned int* next, int n_blocks, int front_mode, bool count, hipStream_t st);
 // mode 5: mode 3 with the triangle-BVH phase as a service shared by the 4 waves of a workgroup (k_serve); `mail` = 2 float4 per
 // thread of the grid (ray origin / direction of the posted rays); needs P.serve = 1 and P.block_threads = 256
-hipError_t launch_serve(const DevScene& S, const FrameParams& P, const FrameTable& T, float4* result, DevCounters* ctr,
+hipError_t launch_serve(const DevScene& S, const FrameParams& P, const FrameUniforms* T, float4* result, DevCounters* ctr,
                         unsigned int* next, float4* mail, int n_blocks, int front_mode, bool count, hipStream_t st);
 // fused AdditionShader blends of n consecutive frames into one image: dst = blend(... blend(blend(dst, src_0), src_1) ..., src_{n-1})
 // in that order per pixel — the same operations as n launch_blit_add calls; src_f = src + f * frame_stride

@@ -127,9 +127,9 @@ __device__ __forceinline__ void test_leaf(const DevScene& S, int32_t leaf, v3 o,
   // two triangles per round: both records are requested before either is tested, so a leaf of 4 costs two memory
   // round trips on the dependent chain instead of four
   for (uint32_t k = 0; k < cnt; k += 2) {
-    const float4* ta = S.tri_verts + 3 * (size_t)(first + k);
+    const float4* ta = (const float4*)((const char*)S.tri_verts + (first + k) * 48u);   // uniform base + 32-bit byte offset (< 4 GiB: checked on the host)
     bool two = k + 1 < cnt;
-    const float4* tb = two ? ta + 3 : ta;
+    const float4* tb = (const float4*)((const char*)S.tri_verts + (first + k + (two ? 1u : 0u)) * 48u);
     float4 a0 = ta[0], a1 = ta[1], a2 = ta[2];
     float4 b0 = tb[0], b1 = tb[1], b2 = tb[2];
     test_triangle<COUNT>(a0, a1, a2, (int)(first + k), o, d, best, best_i, lc);
@@ -472,11 +472,10 @@ __device__ __forceinline__ void camera_ray(const FrameParams& P, int x, int y, f
   dir = mul_m4_k(c2w, dir.x, dir.y, dir.z, 0.0f);
   d = normalize(dir);
 }
-// The same for a batched launch (mode 3): the uniforms of the path's frame come from the launch's frame table, a by-value
-// kernel argument at byte offset T_OFF of the kernarg segment.  `f` must be wave-uniform.
-template <unsigned T_OFF>
-__device__ __forceinline__ void camera_ray_frame(int f, const FrameParams& P, int x, int y, bool new_pixel, float& seed, v3& o, v3& d) {
-  kfloatp q = kernarg_floats((unsigned)__builtin_amdgcn_readfirstlane((int)(T_OFF + (unsigned)f * (unsigned)sizeof(FrameUniforms))));
+// The same for a batched launch (modes 3, 5): the uniforms of the path's frame come from the launch's frame table in device
+// memory, read with scalar loads (table pointer and frame index are wave-uniform).  `f` must be wave-uniform.
+__device__ __forceinline__ void camera_ray_frame(const FrameUniforms* T, int f, const FrameParams& P, int x, int y, bool new_pixel, float& seed, v3& o, v3& d) {
+  kfloatp q = (kfloatp)(unsigned long long)(T + __builtin_amdgcn_readfirstlane(f));
   if (new_pixel) seed = q[34];                     // RS:16: every pixel starts from the frame's _Seed; it carries over between a pixel's rays (RS:444)
   float px = (float)x, py = (float)y;
   float r0 = rand_next(seed, px, py);
@@ -507,8 +506,6 @@ __device__ __forceinline__ void for_each_frame(bool pred, int frame, F&& body) {
 
 // kernels take (DevScene, FrameParams, ...) or (FrameParams, ...): by-value aggregates are laid out like C struct members
 static constexpr unsigned kPOffAfterScene = (unsigned)((sizeof(DevScene) + alignof(FrameParams) - 1) / alignof(FrameParams) * alignof(FrameParams));
-// k_sched takes (DevScene, FrameParams, FrameTable, ...)
-static constexpr unsigned kTOffAfterParams = (unsigned)((kPOffAfterScene + sizeof(FrameParams) + alignof(FrameTable) - 1) / alignof(FrameTable) * alignof(FrameTable));
 
 // tile -> pixel: one 8x8 tile per wave (the reference's [numthreads(8,8,1)] group, RS:431).
 // Blocks are dealt round-robin to the 8 XCDs (b % 8 shares an XCD, each XCD has a private 4 MiB L2).
@@ -981,7 +978,7 @@ static constexpr unsigned int kWatchdogIters = 1u << 24;    // scheduler trips p
 // FMODE: how FRONT treats MeshObjects — 0: a ray that must enter a triangle BVH goes to the BLAS phase at once (one mesh);
 // 1: it first walks the LDS-resident top of that BVH inside FRONT (several meshes); 2: listed form of 1 (front_listed above).
 template <bool COUNT, int BLOCK, int FMODE, bool MULTI>
-__global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, FrameParams P, FrameTable T, float4* __restrict__ result, DevCounters* ctr,
+__global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, FrameParams P, const FrameUniforms* __restrict__ T, float4* __restrict__ result, DevCounters* ctr,
                                                unsigned int* __restrict__ next) {
   // LDS of the workgroup: [top of the triangle-BVH forest: top_nodes x 64 B, shared by its waves][stacks of wave 0][wave 1]...
   // The waves of a workgroup share nothing else and never synchronise after this copy.
@@ -1064,7 +1061,7 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
           st = ST_FRONT;
           ray_i = 0; kf = frame << 24; xy = x | (y << 16);
           avg = mk3(0, 0, 0); res = mk3(0, 0, 0); energy = mk3(1, 1, 1);
-          camera_ray_frame<kTOffAfterParams>(f, P, x, y, true, seed, o, d);
+          camera_ray_frame(T, f, P, x, y, true, seed, o, d);
         }
       });
       nF = __popcll(wballot(st == ST_FRONT || st == ST_RESUME));
@@ -1183,9 +1180,9 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
           v3 sum = (MULTI ? avg : mk3(0, 0, 0)) + res;       // RS:464
           if (MULTI) { avg = sum; ray_i++; next_ray = ray_i < P.num_rays; }
           if (!next_ray) {
-            float n = (float)P.num_rays;
+            float n = (float)P.num_rays;                      // (!MULTI: n = 1 and x / 1 = x — no divisions)
             st_result(result + (size_t)((unsigned)kf >> 24) * P.frame_stride + (size_t)((unsigned)xy >> 16) * P.width + (xy & 0xffff),
-                      make_float4(sum.x / n, sum.y / n, sum.z / n, 1.0f));   // RS:468
+                      MULTI ? make_float4(sum.x / n, sum.y / n, sum.z / n, 1.0f) : make_float4(sum.x, sum.y, sum.z, 1.0f));   // RS:468
             st = ST_DEAD;
           }
         }
@@ -1194,7 +1191,7 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
         for_each_frame(next_ray, (int)((unsigned)kf >> 24), [&](int f, bool mine) {
           if (mine) {
             res = mk3(0, 0, 0); energy = mk3(1, 1, 1); kf &= (int)0xff000000;
-            camera_ray_frame<kTOffAfterParams>(f, P, xy & 0xffff, (int)((unsigned)xy >> 16), false, seed, o, d);
+            camera_ray_frame(T, f, P, xy & 0xffff, (int)((unsigned)xy >> 16), false, seed, o, d);
           }
         });
       }
@@ -1267,7 +1264,7 @@ __device__ __forceinline__ void serve_wait(bool waiting, const int* my_flag, con
   }
 }
 template <bool COUNT, int BLOCK, int FMODE, bool MULTI>
-__global__ __launch_bounds__(BLOCK, URT_SERVE_OCC) void k_serve(DevScene S, FrameParams P, FrameTable T, float4* __restrict__ result, DevCounters* ctr,
+__global__ __launch_bounds__(BLOCK, URT_SERVE_OCC) void k_serve(DevScene S, FrameParams P, const FrameUniforms* __restrict__ T, float4* __restrict__ result, DevCounters* ctr,
                                                unsigned int* __restrict__ next, float4* __restrict__ mail) {
   constexpr int NW = BLOCK / 64;
   static_assert(NW >= 1 && (NW & (NW - 1)) == 0, "waves per workgroup: a power of two");
@@ -1365,7 +1362,7 @@ __global__ __launch_bounds__(BLOCK, URT_SERVE_OCC) void k_serve(DevScene S, Fram
           st = ST_FRONT;
           ray_i = 0; kf = frame << 24; xy = x | (y << 16);
           avg = mk3(0, 0, 0); res = mk3(0, 0, 0); energy = mk3(1, 1, 1);
-          camera_ray_frame<kTOffAfterParams>(f, P, x, y, true, seed, o, d);
+          camera_ray_frame(T, f, P, x, y, true, seed, o, d);
         }
       });
       nF = __popcll(wballot(st == ST_FRONT || st == ST_RESUME));
@@ -1555,9 +1552,9 @@ __global__ __launch_bounds__(BLOCK, URT_SERVE_OCC) void k_serve(DevScene S, Fram
           v3 sum = (MULTI ? avg : mk3(0, 0, 0)) + res;       // RS:464
           if (MULTI) { avg = sum; ray_i++; next_ray = ray_i < P.num_rays; }
           if (!next_ray) {
-            float n = (float)P.num_rays;
+            float n = (float)P.num_rays;                      // (!MULTI: n = 1 and x / 1 = x — no divisions)
             st_result(result + (size_t)((unsigned)kf >> 24) * P.frame_stride + (size_t)((unsigned)xy >> 16) * P.width + (xy & 0xffff),
-                      make_float4(sum.x / n, sum.y / n, sum.z / n, 1.0f));   // RS:468
+                      MULTI ? make_float4(sum.x / n, sum.y / n, sum.z / n, 1.0f) : make_float4(sum.x, sum.y, sum.z, 1.0f));   // RS:468
             st = ST_DEAD;
           }
         }
@@ -1566,7 +1563,7 @@ __global__ __launch_bounds__(BLOCK, URT_SERVE_OCC) void k_serve(DevScene S, Fram
         for_each_frame(next_ray, (int)((unsigned)kf >> 24), [&](int f, bool mine) {
           if (mine) {
             res = mk3(0, 0, 0); energy = mk3(1, 1, 1); kf &= (int)0xff000000;
-            camera_ray_frame<kTOffAfterParams>(f, P, xy & 0xffff, (int)((unsigned)xy >> 16), false, seed, o, d);
+            camera_ray_frame(T, f, P, xy & 0xffff, (int)((unsigned)xy >> 16), false, seed, o, d);
           }
         });
       }
@@ -2079,7 +2076,7 @@ size_t sched_lds_bytes(const DevScene& S, const FrameParams& P) {
 }
 
 template <bool COUNT, int BLOCK, int FMODE, bool MULTI>
-static hipError_t launch_sched_t(const DevScene& S, const FrameParams& P, const FrameTable& T, float4* result, DevCounters* ctr,
+static hipError_t launch_sched_t(const DevScene& S, const FrameParams& P, const FrameUniforms* T, float4* result, DevCounters* ctr,
                                  unsigned int* next, int n_blocks, size_t lds, hipStream_t st) {
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)k_sched<COUNT, BLOCK, FMODE, MULTI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -2090,21 +2087,21 @@ static hipError_t launch_sched_t(const DevScene& S, const FrameParams& P, const 
 }
 
 template <bool COUNT, int BLOCK, int FMODE>
-static hipError_t launch_sched_m(const DevScene& S, const FrameParams& P, const FrameTable& T, float4* result, DevCounters* ctr,
+static hipError_t launch_sched_m(const DevScene& S, const FrameParams& P, const FrameUniforms* T, float4* result, DevCounters* ctr,
                                  unsigned int* next, int n_blocks, size_t lds, hipStream_t st) {
   return P.num_rays > 1 ? launch_sched_t<COUNT, BLOCK, FMODE, true>(S, P, T, result, ctr, next, n_blocks, lds, st)
                         : launch_sched_t<COUNT, BLOCK, FMODE, false>(S, P, T, result, ctr, next, n_blocks, lds, st);
 }
 
 template <bool COUNT, int BLOCK>
-static hipError_t launch_sched_b(const DevScene& S, const FrameParams& P, const FrameTable& T, float4* result, DevCounters* ctr,
+static hipError_t launch_sched_b(const DevScene& S, const FrameParams& P, const FrameUniforms* T, float4* result, DevCounters* ctr,
                                  unsigned int* next, int n_blocks, size_t lds, int front_mode, hipStream_t st) {
   if (front_mode == 2) return launch_sched_m<COUNT, BLOCK, 2>(S, P, T, result, ctr, next, n_blocks, lds, st);
   if (front_mode == 1) return launch_sched_m<COUNT, BLOCK, 1>(S, P, T, result, ctr, next, n_blocks, lds, st);
   return launch_sched_m<COUNT, BLOCK, 0>(S, P, T, result, ctr, next, n_blocks, lds, st);
 }
 
-hipError_t launch_sched(const DevScene& S, const FrameParams& P, const FrameTable& T, float4* result, DevCounters* ctr,
+hipError_t launch_sched(const DevScene& S, const FrameParams& P, const FrameUniforms* T, float4* result, DevCounters* ctr,
                         unsigned int* next, int n_blocks, int front_mode, bool count, hipStream_t st) {
   if (n_blocks <= 0) return hipSuccess;
   if (P.block_threads != 64 && P.block_threads != 256) return hipErrorInvalidValue;   // independent waves; a workgroup shares the LDS top-of-tree copy
@@ -2121,7 +2118,7 @@ hipError_t launch_sched(const DevScene& S, const FrameParams& P, const FrameTabl
 }
 
 template <bool COUNT, int FMODE, bool MULTI>
-static hipError_t launch_serve_t(const DevScene& S, const FrameParams& P, const FrameTable& T, float4* result, DevCounters* ctr,
+static hipError_t launch_serve_t(const DevScene& S, const FrameParams& P, const FrameUniforms* T, float4* result, DevCounters* ctr,
                                  unsigned int* next, float4* mail, int n_blocks, size_t lds, hipStream_t st) {
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)k_serve<COUNT, 256, FMODE, MULTI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -2132,21 +2129,21 @@ static hipError_t launch_serve_t(const DevScene& S, const FrameParams& P, const 
 }
 
 template <bool COUNT, int FMODE>
-static hipError_t launch_serve_m(const DevScene& S, const FrameParams& P, const FrameTable& T, float4* result, DevCounters* ctr,
+static hipError_t launch_serve_m(const DevScene& S, const FrameParams& P, const FrameUniforms* T, float4* result, DevCounters* ctr,
                                  unsigned int* next, float4* mail, int n_blocks, size_t lds, hipStream_t st) {
   return P.num_rays > 1 ? launch_serve_t<COUNT, FMODE, true>(S, P, T, result, ctr, next, mail, n_blocks, lds, st)
                         : launch_serve_t<COUNT, FMODE, false>(S, P, T, result, ctr, next, mail, n_blocks, lds, st);
 }
 
 template <bool COUNT>
-static hipError_t launch_serve_b(const DevScene& S, const FrameParams& P, const FrameTable& T, float4* result, DevCounters* ctr,
+static hipError_t launch_serve_b(const DevScene& S, const FrameParams& P, const FrameUniforms* T, float4* result, DevCounters* ctr,
                                  unsigned int* next, float4* mail, int n_blocks, size_t lds, int front_mode, hipStream_t st) {
   if (front_mode == 2) return launch_serve_m<COUNT, 2>(S, P, T, result, ctr, next, mail, n_blocks, lds, st);
   if (front_mode == 1) return launch_serve_m<COUNT, 1>(S, P, T, result, ctr, next, mail, n_blocks, lds, st);
   return launch_serve_m<COUNT, 0>(S, P, T, result, ctr, next, mail, n_blocks, lds, st);
 }
 
-hipError_t launch_serve(const DevScene& S, const FrameParams& P, const FrameTable& T, float4* result, DevCounters* ctr,
+hipError_t launch_serve(const DevScene& S, const FrameParams& P, const FrameUniforms* T, float4* result, DevCounters* ctr,
                         unsigned int* next, float4* mail, int n_blocks, int front_mode, bool count, hipStream_t st) {
   if (n_blocks <= 0) return hipSuccess;
   if (P.block_threads != 256 || !P.serve || !mail) return hipErrorInvalidValue;

@@ -72,13 +72,13 @@ struct FrameParams {
   int pool_other_min;       // mode 4: lanes of FRONT / SHADE work that make those phases worth a trip while rays queue for the BVH
   unsigned int watchdog_steps;  // cap on traversal trips per scheduled BLAS phase: a few times (nodes + leaves) of the scene
   // mode 3, frame batching: ONE launch traces n_frames consecutive frames of the same scene/resolution (the library defers
-  // dispatches, context.cpp).  Frame f's uniforms are FrameTable::f[f] (a by-value kernel argument); its Result image starts
+  // dispatches, context.cpp).  Frame f's uniforms are entry f of the launch's table in device memory; its Result image starts
   // at result + f * frame_stride.  The c2w/invp/pixel_off/seed above are those of frame 0 (all the other kernel modes read).
   int n_frames;                 // >= 1
   unsigned int frame_stride;    // float4 elements between the Result images of consecutive frames of the launch
 };
 
-// per-frame uniforms of a batched launch (RM:773-778): 144 bytes each, read with scalar loads from the kernel-argument segment
+// per-frame uniforms of a batched launch (RM:773-778): 144 bytes each, read with scalar loads through a wave-uniform pointer
 // (the frame index is made wave-uniform first)
 struct FrameUniforms {
   float c2w[16];            // _CameraToWorld
@@ -87,8 +87,8 @@ struct FrameUniforms {
   float seed;               // _Seed
   float pad;
 };
-static constexpr int kMaxFramesPerLaunch = 16;      // 16 x 144 B = 2304 B of the 4 KiB kernel-argument segment
-struct FrameTable { FrameUniforms f[kMaxFramesPerLaunch]; };
+static constexpr int kMaxFramesPerLaunch = 64;      // the table lives in device memory (context.cpp stages it through pinned host slots): 64 x 144 B
+struct FrameTable { FrameUniforms f[kMaxFramesPerLaunch]; };   // host-side image of one launch's table
 
 static constexpr unsigned int kWorkShards = 64;   // work counters of the persistent kernels (power of two), 128 B apart
 static constexpr int kCounterShards = 256;   // power of two; a block adds to shard blockIdx & (N-1)
