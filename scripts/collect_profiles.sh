@@ -9,7 +9,7 @@ CFG=${1:-C3}; MODE=${2:-full}
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out/prof_$CFG
 rm -rf "$OUT"; mkdir -p "$OUT"
-BENCH="bench.py --config $CFG --steps 20 --warmup 5"
+BENCH="bench.py --config $CFG"   # the default command: 8 warm-up frames, 256 timed frames (four launches of 64)
 timeout -k 10 300 python3 $BENCH > "$OUT/bench.json.log" 2> "$OUT/bench.err" || exit 1
 echo "bench done" >> "$OUT/progress.txt"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 $BENCH --no-cpu-baseline > "$OUT/trace.log" 2>&1 || exit 1

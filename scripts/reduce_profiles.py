@@ -65,6 +65,6 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
         "hbm_bytes_per_launch": hbm, "rocprof_timed_launch_ms": None if not stats or last_ns is None else last_ns / 1e6,
         "rocprof_avg_launch_ms": None if avg_ns is None else avg_ns / 1e6, "rocprof_launches": calls,
         "bench_launch_ms": rl.get("launch_ms"), "algorithmic_bytes_per_launch": rl.get("algorithmic_bytes_per_launch"), "frac": rl.get("frac"),
-        "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --config {cfg} --steps 20 --warmup 5 --no-cpu-baseline; the TIMED launch of the run (its last launch of the kernel; the earlier one traces the warm-up frames)"}
+        "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --config {cfg} --no-cpu-baseline (defaults: 8 warm-up + 256 timed frames); the LAST launch of the timed kernel in the run = 64 timed frames"}
     json.dump(allcfg, open(path, "w"), indent=1)
     print("hbm bytes per launch", hbm)
