@@ -261,8 +261,8 @@ URT_HD float blas_rcp(float d) {
 // ---------------------------------------------------------------------------------------------
 // x / c for a CONSTANT c whose correctly rounded reciprocal is y, without the divider: q = RN(x y), r = x - q c (exact, one
 // fma), q' = RN(q + r y) (Markstein's correction step).  tests/test_oracle_math.py checks q' against the IEEE quotient for
-// EVERY finite float x, for the two constants used below: c = 17 agrees everywhere, c = 100 everywhere above 4.8e-38; zeros (sign), the
-// bottom of the range, infinities and NaN take the divider.  Ten instructions fewer per division on the GPU, same value.
+// EVERY float x, for the constants it is used with (17 and 100 below, -PI in the HIP sky lookup): c = 17 agrees everywhere, c = 100
+// everywhere above 4.8e-38, c = -PI above 3.1e-32; zeros (sign), the bottom of the range (|x| < 1e-30), infinities and NaN take the divider.  Ten instructions fewer per division on the GPU, same value.
 URT_HD float f_div_const(float x, float c, float y) {
   float ax = f_abs(x);
   if (!(ax >= 1e-30f && ax <= 3.0e38f)) return x / c;

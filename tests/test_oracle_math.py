@@ -90,11 +90,12 @@ def test_rand_structure():
 
 
 def test_division_by_the_rand_constants_is_the_ieee_quotient_for_every_float():
-    """rand() divides by 17 and by 100 (RS:78).  include/urt_math.h evaluates both as a reciprocal multiplication plus one
+    """rand() divides by 17 and by 100 (RS:78), the sky lookup by -PI (RS:424-425).  include/urt_math.h evaluates both as a reciprocal multiplication plus one
     fma correction step (f_div_const; the divider only for zeros, the bottom of the range, infinities and NaN) — ten GPU
     instructions fewer per division.  EXHAUSTIVE: all 2^32 bit patterns of x give the bits of x / c, for both constants."""
     assert pyoracle.check_div_const(17.0, threads=8) == 0
     assert pyoracle.check_div_const(100.0, threads=8) == 0
+    assert pyoracle.check_div_const(-3.14159265, threads=8) == 0     # the sky lookup's "/ -PI" (RS:424-425; HIP side only)
     # the golden values of rand() itself are unchanged: the same formula with true divisions, evaluated in numpy float32
     seed = np.float32([0.5, 1.0, 7.25, 63.5, 1e-3])
     a = ((seed + seed / np.float32(17)) / np.float32(100)).astype(np.float32)

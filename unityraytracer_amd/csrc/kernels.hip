@@ -425,8 +425,10 @@ __device__ __forceinline__ bool shade_sky(const DevScene& S, v3 d, v3& energy, v
   v3 e0 = energy;
   if (COUNT) lc.hit_sky++;
   energy = mk3(0, 0, 0);
-  float theta = f_acos(d.y) / -kPI;
-  float phi = f_atan2(d.x, -d.z) / -kPI * 0.5f;
+  // RS:424-425 divide by the constant -PI: f_div_const (urt_math.h) = the IEEE quotient for every float (exhaustive test), ten
+  // instructions fewer per division; the oracle keeps the divider
+  float theta = f_div_const(f_acos(d.y), -kPI, 1.0f / -kPI);
+  float phi = f_div_const(f_atan2(d.x, -d.z), -kPI, 1.0f / -kPI) * 0.5f;
   v3 s = sample_sky(S, phi, theta);
   result = result + e0 * s;
   return any_nonzero(energy);                  // false: the path ends here (RS:421,457)
