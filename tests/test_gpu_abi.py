@@ -180,3 +180,31 @@ def test_counters_and_watchdog(gpu_ctx):
     with pytest.raises(UrtError):
         gpu_ctx.set_option("no_such_option", 1)
     m.OnDisable()
+
+
+def test_two_hosts_interleaved_on_one_context(gpu_ctx):
+    """Two RayTraceMasters alive on ONE context, rendering alternately: every uniform and binding really changes hands each
+    frame (the Python mirror skips calls that would set a name to the value the context already holds — it must not skip
+    these), and the library's frame batching has to break its batches at every switch.  Each master's running mean equals
+    what it produces alone."""
+    sa = scenes.mixed_test_scene(96, 64)
+    sb = scenes.mixed_test_scene(64, 40)                       # (both bind all seven buffers: a null buffer is never bound, RM:252-259,
+    sb.num_rays, sb.num_bounces = 2, 3                         #  so a scene without meshes would inherit the other one's)
+    sb.spheres = sb.spheres.copy()
+    sb.spheres["position"][:, 0] += 0.7                        # other spheres, other heap, other resolution, other loop counts
+    sb.sphere_bvh = scenes.build_object_bvh(*scenes.sphere_bounds(sb.spheres))
+    def alone(sc, n):
+        m = RayTraceMaster(gpu_ctx, sc)
+        for _ in range(n):
+            m.OnRenderImage()
+        img = m._converged.GetPixels()
+        m.OnDisable()
+        return img
+    want_a, want_b = alone(sa, 5), alone(sb, 5)
+    ma, mb = RayTraceMaster(gpu_ctx, sa), RayTraceMaster(gpu_ctx, sb)
+    for _ in range(5):
+        ma.OnRenderImage()
+        mb.OnRenderImage()
+    got_a, got_b = ma._converged.GetPixels(), mb._converged.GetPixels()
+    ma.OnDisable(); mb.OnDisable()
+    assert bits_equal(got_a, want_a) and bits_equal(got_b, want_b)
