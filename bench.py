@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--config", default="C3", help="BASELINE.json config to trace (C2..C5, C3D = C3 in close-up); the metric is quoted on C3")
-    ap.add_argument("--kernel-mode", type=int, default=None, help="0 per-pixel, 1 per-bounce queues, 2 persistent, 3 persistent + phase-scheduled lanes (default)")
+    ap.add_argument("--kernel-mode", type=int, default=None, help="0 per-pixel, 1 per-bounce queues, 2 persistent, 3 persistent + phase-scheduled lanes (default), 4 path pool in LDS, 5 shared traversal service")
     ap.add_argument("--frames-per-launch", type=int, default=None, help="library option frames_per_launch (0 auto, 1 = one launch per frame, 2..64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
