@@ -85,8 +85,8 @@ SCHED_VARIANTS = [
     {"refill_min": 1, "blas_min": 1, "blas_exit": 1, "shade_min": 1, "waves_per_cu": 3},
     {"refill_min": 64, "blas_min": 64, "blas_exit": 64, "shade_min": 64, "waves_per_cu": 32},
 ]
-SCHED_DEFAULTS = {"sched_block": 0, "top_nodes": 64, "top_front": -1, "lds_tlas": 1, "tile_order": 0, "xcd_run": 1,
-                  "refill_min": 32, "blas_min": 28, "blas_exit": 6, "waves_per_cu": 0, "shade_min": 32}
+SCHED_DEFAULTS = {"sched_block": 0, "top_nodes": 64, "top_front": -1, "lds_tlas": 1, "tile_order": 0, "xcd_run": 0,
+                  "refill_min": 16, "blas_min": 28, "blas_exit": 0, "waves_per_cu": 0, "shade_min": 32}
 
 
 @pytest.mark.parametrize("variant", range(len(SCHED_VARIANTS)))
