@@ -110,7 +110,7 @@ struct urt_context {
   float trace_ms = 0;
 
   int opt_count_stats = 0, opt_time_dispatch = 0, opt_kernel_mode = 3;
-  int opt_block_threads = 64, opt_xcd_run = 0 /* auto */, opt_refill_min = 16, opt_waves_per_cu = 0 /* auto */, opt_blas_min = 28, opt_blas_exit = 0 /* auto */;
+  int opt_block_threads = 64, opt_xcd_run = 0 /* auto */, opt_work_shards = 64, opt_refill_min = 16, opt_waves_per_cu = 0 /* auto */, opt_blas_min = 28, opt_blas_exit = 0 /* auto */;
   int opt_pool_k = 2, opt_pool_refill = 32, opt_pool_blas_min = 48, opt_pool_blas_exit = 8, opt_pool_inloop = 16, opt_pool_other_min = 24;   // kernel_mode 4
   int opt_sched_block = 0;                  // kernel_mode 3: threads per workgroup (64 or 256; 0 = 256 when there is a BVH top to share)
   int opt_stack_pad = 0;                    // test hook: extra (unused) entries per traversal stack, to reach the > 64 KiB LDS launch path
@@ -660,6 +660,7 @@ int do_dispatch(urt_context* ctx, int kernel, int gx, int gy, int gz, int first_
   P.blas_exit = ctx->opt_blas_exit > 0 ? ctx->opt_blas_exit : (S.n_meshes > 1 ? 9 : 14); P.shade_min = ctx->opt_shade_min; P.sky_min = ctx->opt_sky_min;
   P.n_frames = 1; P.frame_stride = 0;
   if (P.n_strips == 0 || P.tiles_x == 0) return URT_OK;
+  P.n_shards = ctx->opt_work_shards;
   if (ctx->opt_xcd_run <= 0) {
     // persistent kernels: a work-counter shard hands out RUNS of consecutive 8x8 tiles, so a wave's successive refills are
     // neighbours on the image (their rays meet the same BVH subtrees and sky lines) and an XCD's L2 serves a few bands of the
@@ -667,7 +668,7 @@ int do_dispatch(urt_context* ctx, int kernel, int gx, int gy, int gz, int first_
     // measured against 1: C2 -9 %, C3 -4 %, C3D -7 %, C4 -2 %, C5 -4 %; odd lengths (63) lose most of it, runs of 256+ unbalance a
     // 1080p frame (profiles/r02_logs/r2_xcd_run.log).
     long tiles = (long)P.tiles_x * P.n_strips, g = 1;
-    while (g < 64 && 2 * g <= tiles / (long)(kWorkShards * 4)) g *= 2;
+    while (g < 64 && 2 * g <= tiles / (long)(P.n_shards * 4)) g *= 2;
     P.xcd_run = (ctx->opt_kernel_mode >= 2) ? (int)g : 1;
   }
   if ((uint64_t)P.tiles_x * (uint64_t)P.n_strips * 64u >= 0xffffffffull)
@@ -1262,6 +1263,9 @@ int urt_set_option(urt_context* ctx, const char* name, int value) {
   } else if (std::strcmp(name, "pool_inloop") == 0) {
     if (value < 1 || value > 64) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "pool_inloop must be in [1, 64]");
     ctx->opt_pool_inloop = value;
+  } else if (std::strcmp(name, "work_shards") == 0) {
+    if (value < 1 || value > (int)kWorkShards || (value & (value - 1))) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "work_shards must be a power of two in [1, 64]");
+    ctx->opt_work_shards = value;
   } else if (std::strcmp(name, "xcd_run") == 0) {
     if (value < 0 || value > 4096) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "xcd_run must be in [0, 4096] (0 = auto)");
     ctx->opt_xcd_run = value;

@@ -610,15 +610,15 @@ static_assert(kWorkShards == 64, "the dry-shard probe reads one counter per lane
 // Tiles are dealt to the shards in RUNS of G = P.xcd_run consecutive tiles (run r belongs to shard r % kWorkShards).  G = 1
 // interleaves single tiles; a large G gives every shard contiguous image bands, and because workgroup b runs on XCD b % 8
 // and starts on shard b % kWorkShards, each XCD's L2 then serves a few bands of the image instead of all of it.
-__device__ __forceinline__ unsigned int shard_slots(unsigned int ntiles, unsigned int shard, unsigned int G) {   // slots owned by a shard
-  unsigned int cycle = kWorkShards * G;
+__device__ __forceinline__ unsigned int shard_slots(unsigned int ntiles, unsigned int shard, unsigned int G, unsigned int NS) {   // slots owned by a shard
+  unsigned int cycle = NS * G;
   unsigned int full = ntiles / cycle, rem = ntiles - full * cycle;
   unsigned int extra = rem > shard * G ? min(rem - shard * G, G) : 0u;
   return (full * G + extra) * 64u;
 }
-__device__ __forceinline__ unsigned int shard_tile(unsigned int shard, unsigned int q, unsigned int G) {   // q-th tile of a shard
+__device__ __forceinline__ unsigned int shard_tile(unsigned int shard, unsigned int q, unsigned int G, unsigned int NS) {   // q-th tile of a shard
   unsigned int run = q / G;
-  return (run * kWorkShards + shard) * G + (q - run * G);
+  return (run * NS + shard) * G + (q - run * G);
 }
 
 // slot -> pixel; false for slots that fall outside the dispatched region (ragged right/top edge)
@@ -638,15 +638,15 @@ __device__ __forceinline__ bool wave_fetch_pixels(const FrameParams& P, unsigned
                                                   unsigned int tiles_per_frame = 0, int* frame = nullptr) {
   const int lane = threadIdx.x & 63;
   unsigned int n = (unsigned int)__popcll(want);
-  const unsigned int G = (unsigned int)P.xcd_run;
-  unsigned int own = shard_slots(ntiles, wc.shard, G);
+  const unsigned int G = (unsigned int)P.xcd_run, NS = (unsigned int)P.n_shards;
+  unsigned int own = shard_slots(ntiles, wc.shard, G, NS);
   unsigned int base = 0;
   if (lane == 0) base = atomicAdd(next + wc.shard * 32u, n);
   base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);   // called by the whole wave: lane 0's value, and wave-uniform for the compiler (what hangs off it — shard moves, `exhausted` — stays in scalar registers)
   unsigned int shard = wc.shard;
   if (base + n >= own) {   // this shard is (now) dry: every lane looks at one counter, the wave moves to the next shard with work
     unsigned int seen = __hip_atomic_load(next + lane * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned long long avail = wballot(seen < shard_slots(ntiles, (unsigned int)lane, G)) & ~(1ull << shard);
+    unsigned long long avail = wballot((unsigned int)lane < NS && seen < shard_slots(ntiles, (unsigned int)lane, G, NS)) & ~(1ull << shard);
     if (!avail) {
       exhausted = true;    // counters only grow, so this is final
     } else {
@@ -656,7 +656,7 @@ __device__ __forceinline__ bool wave_fetch_pixels(const FrameParams& P, unsigned
   }
   unsigned int local = base + (unsigned int)__popcll(want & ((1ull << lane) - 1ull));
   if (!mine || local >= own) return false;
-  unsigned int tile = shard_tile(shard, local >> 6, G);
+  unsigned int tile = shard_tile(shard, local >> 6, G, NS);
   if (frame) { unsigned int f = tile / tiles_per_frame; tile -= f * tiles_per_frame; *frame = (int)f; ntiles = tiles_per_frame; }
   if (P.tile_order == 1) tile = ntiles - 1u - tile;            // top strip first
   return slot_pixel(P, tile, local & 63u, x, y);
@@ -679,7 +679,7 @@ __global__ __launch_bounds__(256) void k_persist(DevScene S, FrameParams P, floa
   lane_stacks(P, tl, bl);
   LocalCounters lc;
   const unsigned int ntiles = (unsigned int)(P.tiles_x * P.n_strips);
-  WorkCursor wc; wc.shard = blockIdx.x & (kWorkShards - 1u);
+  WorkCursor wc; wc.shard = blockIdx.x & ((unsigned int)P.n_shards - 1u);
   bool alive = false, exhausted = false;
 #ifdef URT_STAMPS
   unsigned long long t_start = wall_clock64(), t_exh = 0; unsigned int n_iter = 0, n_fetch = 0;
@@ -1021,7 +1021,9 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
   LocalCounters lc;
   const unsigned int tiles_per_frame = (unsigned int)(P.tiles_x * P.n_strips);
   const unsigned int ntiles = tiles_per_frame * (unsigned int)P.n_frames;
-  WorkCursor wc; wc.shard = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (kWorkShards - 1u);
+  // the waves of a workgroup draw from ONE shard (and, workgroups b, b + 256, ... landing on the same CU, so does the whole CU):
+  // neighbours on the chip work on neighbouring tiles (a shard per wave: C2 +6 %, C3 +4 %, C4 +3 %, C5 +3 % time)
+  WorkCursor wc; wc.shard = blockIdx.x & ((unsigned int)P.n_shards - 1u);
   bool exhausted = false;
   int st = ST_DEAD;
   // path state
@@ -1323,7 +1325,7 @@ __global__ __launch_bounds__(BLOCK, URT_SERVE_OCC) void k_serve(DevScene S, Fram
   LocalCounters lc;
   const unsigned int tiles_per_frame = (unsigned int)(P.tiles_x * P.n_strips);
   const unsigned int ntiles = tiles_per_frame * (unsigned int)P.n_frames;
-  WorkCursor wc; wc.shard = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (kWorkShards - 1u);
+  WorkCursor wc; wc.shard = blockIdx.x & ((unsigned int)P.n_shards - 1u);
   bool exhausted = false;
   int st = ST_DEAD;
   // path state
@@ -1641,7 +1643,7 @@ __global__ __launch_bounds__(64) void k_pool(DevScene S, FrameParams P, float4* 
   for (int j = 0; j < K; j++) stt[j * 64 + lane] = PS_FREE;
   LocalCounters lc;
   const unsigned int ntiles = (unsigned int)(P.tiles_x * P.n_strips);
-  WorkCursor wc; wc.shard = blockIdx.x & (kWorkShards - 1u);
+  WorkCursor wc; wc.shard = blockIdx.x & ((unsigned int)P.n_shards - 1u);
   bool exhausted = false, watchdog = false;
   unsigned int wave_iters = 0;
 #ifdef URT_STAMPS
