@@ -77,6 +77,24 @@ def test_long_batches_up_to_64_frames_per_launch(gpu_ctx):
         gpu_ctx.set_option("frames_per_launch", 65)
 
 
+def test_frame_interleaving_is_invisible(gpu_ctx):
+    """`frame_group` = frames of a launch whose tile runs are interleaved (default: all of them — the same tiles of consecutive
+    frames are traced back to back while their BVH subtrees are hot).  1, a group size that does not divide the batch, and the
+    default give the same pixels as single launches; the ragged last run of a frame (tiles not a multiple of the run length)
+    and the ragged last group only produce empty slots."""
+    sc = scenes.mixed_test_scene(200, 120)                     # 25 x 15 tiles: not a multiple of any run length
+    n = 11
+    ref_conv, ref_last, _, c1 = run_frames(gpu_ctx, sc, n, 1, peek_at=())
+    try:
+        for fg, run in ((1, 0), (2, 0), (5, 4), (64, 0), (64, 16), (3, 64)):
+            gpu_ctx.set_option("frame_group", fg); gpu_ctx.set_option("xcd_run", run)
+            conv, last, _, c = run_frames(gpu_ctx, sc, n, 8, peek_at=())
+            assert bits_equal(conv, ref_conv) and bits_equal(last, ref_last), (fg, run)
+            assert c["rays"] == c1["rays"] and c["launches"] == 2 and c["watchdog_trips"] == 0, (fg, run, c)
+    finally:
+        gpu_ctx.set_option("frame_group", 64); gpu_ctx.set_option("xcd_run", 0)
+
+
 def test_batch_of_strips_equals_full_frames(gpu_ctx):
     """Multi-GPU strips (partial-coverage dispatches) are batched too: the pixels outside a rank's strips stay the zeros of
     the freshly created RenderTexture in every renamed slot."""

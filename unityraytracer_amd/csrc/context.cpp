@@ -110,7 +110,7 @@ struct urt_context {
   float trace_ms = 0;
 
   int opt_count_stats = 0, opt_time_dispatch = 0, opt_kernel_mode = 3;
-  int opt_block_threads = 64, opt_xcd_run = 0 /* auto */, opt_work_shards = 64, opt_refill_min = 16, opt_waves_per_cu = 0 /* auto */, opt_blas_min = 28, opt_blas_exit = 0 /* auto */;
+  int opt_block_threads = 64, opt_xcd_run = 0 /* auto */, opt_work_shards = 64, opt_frame_group = 64, opt_refill_min = 16, opt_waves_per_cu = 0 /* auto */, opt_blas_min = 28, opt_blas_exit = 0 /* auto */;
   int opt_pool_k = 2, opt_pool_refill = 32, opt_pool_blas_min = 48, opt_pool_blas_exit = 8, opt_pool_inloop = 16, opt_pool_other_min = 24;   // kernel_mode 4
   int opt_sched_block = 0;                  // kernel_mode 3: threads per workgroup (64 or 256; 0 = 256 when there is a BVH top to share)
   int opt_stack_pad = 0;                    // test hook: extra (unused) entries per traversal stack, to reach the > 64 KiB LDS launch path
@@ -563,6 +563,7 @@ int flush_pending(urt_context* ctx) {
   URT_HIP(ctx, hipSetDevice(ctx->device));
   FrameParams P = B.P;
   P.n_frames = n;
+  P.frame_group = std::max(1, std::min(P.frame_group, n));
   P.frame_stride = (unsigned int)ctx->slab_stride;
   int rc = launch_sched_frames(ctx, B.S, P, B.T, ctx->slab, B.front_mode, B.count);
   if (rc) return rc;
@@ -608,8 +609,8 @@ int batch_limit(urt_context* ctx, const FrameParams& P) {
     lim = (int)std::min<uint64_t>(kAutoFrames, std::max<uint64_t>(1, (8ull << 30) / std::max<uint64_t>(1, frame_bytes)));
   }
   // the work counter hands out 32-bit pixel slots: frames x tiles x 64 must stay below 2^32
-  uint64_t slots = std::max<uint64_t>(1, (uint64_t)P.tiles_x * (uint64_t)P.n_strips * 64u);
-  lim = (int)std::min<uint64_t>((uint64_t)lim, std::max<uint64_t>(1, 0xfffffffeull / slots));
+  uint64_t slots = std::max<uint64_t>(1, ((uint64_t)P.tiles_x * (uint64_t)P.n_strips + (uint64_t)std::max(1, P.xcd_run)) * 64u);   // (a frame's last run is padded when frames are interleaved)
+  lim = (int)std::min<uint64_t>((uint64_t)lim, std::max<uint64_t>(1, 0xfffffffeull / slots / 2));
   return std::max(1, std::min(lim, (int)kMaxFramesPerLaunch));
 }
 
@@ -660,7 +661,7 @@ int do_dispatch(urt_context* ctx, int kernel, int gx, int gy, int gz, int first_
   P.blas_exit = ctx->opt_blas_exit > 0 ? ctx->opt_blas_exit : (S.n_meshes > 1 ? 9 : 14); P.shade_min = ctx->opt_shade_min; P.sky_min = ctx->opt_sky_min;
   P.n_frames = 1; P.frame_stride = 0;
   if (P.n_strips == 0 || P.tiles_x == 0) return URT_OK;
-  P.n_shards = ctx->opt_work_shards;
+  P.n_shards = ctx->opt_work_shards; P.frame_group = ctx->opt_frame_group;
   if (ctx->opt_xcd_run <= 0) {
     // persistent kernels: a work-counter shard hands out RUNS of consecutive 8x8 tiles, so a wave's successive refills are
     // neighbours on the image (their rays meet the same BVH subtrees and sky lines) and an XCD's L2 serves a few bands of the
@@ -717,6 +718,7 @@ int do_dispatch(urt_context* ctx, int kernel, int gx, int gy, int gz, int first_
     if (limit <= 1) {                                     // not batched: trace this frame now, straight into the texture
       FrameTable T{};
       T.f[0] = fu;
+      P.frame_group = 1;
       int rc = launch_sched_frames(ctx, S, P, T, res->dev, front_mode, count);
       if (rc) return rc;
     } else {
@@ -1263,6 +1265,9 @@ int urt_set_option(urt_context* ctx, const char* name, int value) {
   } else if (std::strcmp(name, "pool_inloop") == 0) {
     if (value < 1 || value > 64) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "pool_inloop must be in [1, 64]");
     ctx->opt_pool_inloop = value;
+  } else if (std::strcmp(name, "frame_group") == 0) {
+    if (value < 1 || value > kMaxFramesPerLaunch) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "frame_group must be in [1, 64]");
+    ctx->opt_frame_group = value;
   } else if (std::strcmp(name, "work_shards") == 0) {
     if (value < 1 || value > (int)kWorkShards || (value & (value - 1))) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "work_shards must be a power of two in [1, 64]");
     ctx->opt_work_shards = value;

@@ -657,7 +657,22 @@ __device__ __forceinline__ bool wave_fetch_pixels(const FrameParams& P, unsigned
   unsigned int local = base + (unsigned int)__popcll(want & ((1ull << lane) - 1ull));
   if (!mine || local >= own) return false;
   unsigned int tile = shard_tile(shard, local >> 6, G, NS);
-  if (frame) { unsigned int f = tile / tiles_per_frame; tile -= f * tiles_per_frame; *frame = (int)f; ntiles = tiles_per_frame; }
+  if (frame) {
+    const unsigned int FG = (unsigned int)P.frame_group;
+    if (FG <= 1u) { unsigned int f = tile / tiles_per_frame; tile -= f * tiles_per_frame; *frame = (int)f; }
+    else {
+      // frames interleaved in groups of FG: the global sequence is run 0 of frames 0..FG-1, run 1 of frames 0..FG-1, ... — the same
+      // tiles of consecutive frames (same pixels, other jitter and seeds) are traced back to back, while their BVH subtrees are hot
+      unsigned int rg = tile / G, w = tile - rg * G;
+      unsigned int runs_pf = (tiles_per_frame + G - 1u) / G, group_runs = runs_pf * FG;
+      unsigned int grp = rg / group_runs, r = rg - grp * group_runs;
+      unsigned int f = grp * FG + r % FG;
+      tile = (r / FG) * G + w;
+      *frame = (int)f;
+      if (tile >= tiles_per_frame || f >= (unsigned int)P.n_frames) return false;
+    }
+    ntiles = tiles_per_frame;
+  }
   if (P.tile_order == 1) tile = ntiles - 1u - tile;            // top strip first
   return slot_pixel(P, tile, local & 63u, x, y);
 }
@@ -1020,7 +1035,9 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
   int* bl = tl + P.tlas_stack * 64;
   LocalCounters lc;
   const unsigned int tiles_per_frame = (unsigned int)(P.tiles_x * P.n_strips);
-  const unsigned int ntiles = tiles_per_frame * (unsigned int)P.n_frames;
+  const unsigned int ntiles = P.frame_group <= 1 ? tiles_per_frame * (unsigned int)P.n_frames
+                                                 : (((unsigned int)P.n_frames + (unsigned int)P.frame_group - 1u) / (unsigned int)P.frame_group) * (unsigned int)P.frame_group *
+                                                   ((tiles_per_frame + (unsigned int)P.xcd_run - 1u) / (unsigned int)P.xcd_run) * (unsigned int)P.xcd_run;
   // the waves of a workgroup draw from ONE shard (and, workgroups b, b + 256, ... landing on the same CU, so does the whole CU):
   // neighbours on the chip work on neighbouring tiles (a shard per wave: C2 +6 %, C3 +4 %, C4 +3 %, C5 +3 % time)
   WorkCursor wc; wc.shard = blockIdx.x & ((unsigned int)P.n_shards - 1u);
@@ -1324,7 +1341,9 @@ __global__ __launch_bounds__(BLOCK, URT_SERVE_OCC) void k_serve(DevScene S, Fram
   float4* const wgmail = mail + (size_t)blockIdx.x * (size_t)(2 * BLOCK);
   LocalCounters lc;
   const unsigned int tiles_per_frame = (unsigned int)(P.tiles_x * P.n_strips);
-  const unsigned int ntiles = tiles_per_frame * (unsigned int)P.n_frames;
+  const unsigned int ntiles = P.frame_group <= 1 ? tiles_per_frame * (unsigned int)P.n_frames
+                                                 : (((unsigned int)P.n_frames + (unsigned int)P.frame_group - 1u) / (unsigned int)P.frame_group) * (unsigned int)P.frame_group *
+                                                   ((tiles_per_frame + (unsigned int)P.xcd_run - 1u) / (unsigned int)P.xcd_run) * (unsigned int)P.xcd_run;
   WorkCursor wc; wc.shard = blockIdx.x & ((unsigned int)P.n_shards - 1u);
   bool exhausted = false;
   int st = ST_DEAD;

@@ -59,6 +59,7 @@ struct FrameParams {
   int tile_order;           // persistent modes: 0 = strips bottom to top (natural), 1 = top to bottom
   int xcd_run;              // blocks per XCD run in the tile order (kernels.hip tile_pixel); persistent modes: tiles per run of a work-counter shard
   int n_shards;             // persistent modes: work-counter shards in use (power of two, 1..kWorkShards)
+  int frame_group;          // batched launches: frames whose tile runs are interleaved (1 = frame after frame)
   int refill_min;           // persistent modes: dead lanes per wave that trigger a refill (1..64)
   int blas_min;             // mode 3: lanes parked in BLAS before the traversal phase is scheduled (1..64)
   int shade_min;            // mode 3: SHADE (surface-hit) lanes that make the phase run ahead of FRONT (1..64)
