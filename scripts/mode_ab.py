@@ -32,7 +32,7 @@ def scene_of(name):
     return scenes.CONFIGS[name]()
 
 
-DEFAULTS = {"blas_min": 28, "blas_exit": 0, "serve_refill": 16, "refill_min": 16, "shade_min": 32, "sky_min": 32, "waves_per_cu": 0}
+DEFAULTS = {"blas_min": 0, "blas_exit": 0, "serve_refill": 16, "refill_min": 16, "shade_min": 32, "sky_min": 32, "waves_per_cu": 0}
 
 
 def run(sc, mode, opts, n):

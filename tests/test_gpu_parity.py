@@ -86,7 +86,7 @@ SCHED_VARIANTS = [
     {"refill_min": 64, "blas_min": 64, "blas_exit": 64, "shade_min": 64, "waves_per_cu": 32},
 ]
 SCHED_DEFAULTS = {"sched_block": 0, "top_nodes": 64, "top_front": -1, "lds_tlas": 1, "tile_order": 0, "xcd_run": 0,
-                  "refill_min": 16, "blas_min": 28, "blas_exit": 0, "waves_per_cu": 0, "shade_min": 32}
+                  "refill_min": 16, "blas_min": 0, "blas_exit": 0, "waves_per_cu": 0, "shade_min": 32}
 
 
 @pytest.mark.parametrize("variant", range(len(SCHED_VARIANTS)))
@@ -229,7 +229,7 @@ def test_shared_traversal_service_mode5(gpu_ctx):
                 gpu_ctx.set_option(k, v)
             gpu, _, gc = render_gpu(gpu_ctx, sc, 5, count=True)
             sv = gpu_ctx.serve_stats()
-            for k, v in {"blas_min": 28, "blas_exit": 0, "serve_refill": 16}.items():
+            for k, v in {"blas_min": 0, "blas_exit": 0, "serve_refill": 16}.items():
                 gpu_ctx.set_option(k, v)
             assert_same(gpu, ref, f"mode 5 {sc.name} {opts}")
             for k in ("rays", "tlas_nodes", "blas_nodes", "tri_tests", "hit_tri", "hit_ground", "hit_sky", "pixels"):
@@ -239,6 +239,6 @@ def test_shared_traversal_service_mode5(gpu_ctx):
             if opts.get("blas_exit", 0) >= 32:
                 assert sv["suspended"] > 0, sv                   # the yield path (suspend -> resumed by any wave) really ran
     finally:
-        for k, v in {"blas_min": 28, "blas_exit": 0, "serve_refill": 16}.items():
+        for k, v in {"blas_min": 0, "blas_exit": 0, "serve_refill": 16}.items():
             gpu_ctx.set_option(k, v)
         gpu_ctx.set_option("kernel_mode", 3); gpu_ctx.set_option("count_stats", 0)

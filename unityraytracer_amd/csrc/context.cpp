@@ -110,7 +110,7 @@ struct urt_context {
   float trace_ms = 0;
 
   int opt_count_stats = 0, opt_time_dispatch = 0, opt_kernel_mode = 3;
-  int opt_block_threads = 64, opt_xcd_run = 0 /* auto */, opt_work_shards = 64, opt_frame_group = 64, opt_refill_min = 16, opt_waves_per_cu = 0 /* auto */, opt_blas_min = 28, opt_blas_exit = 0 /* auto */;
+  int opt_block_threads = 64, opt_xcd_run = 0 /* auto */, opt_work_shards = 64, opt_frame_group = 64, opt_refill_min = 16, opt_waves_per_cu = 0 /* auto */, opt_blas_min = 0 /* auto */, opt_blas_exit = 0 /* auto */;
   int opt_pool_k = 2, opt_pool_refill = 32, opt_pool_blas_min = 48, opt_pool_blas_exit = 8, opt_pool_inloop = 16, opt_pool_other_min = 24;   // kernel_mode 4
   int opt_sched_block = 0;                  // kernel_mode 3: threads per workgroup (64 or 256; 0 = 256 when there is a BVH top to share)
   int opt_stack_pad = 0;                    // test hook: extra (unused) entries per traversal stack, to reach the > 64 KiB LDS launch path
@@ -655,7 +655,10 @@ int do_dispatch(urt_context* ctx, int kernel, int gx, int gy, int gz, int first_
   P.first_group_row = first_row; P.row_stride = row_stride;
   P.n_strips = first_row < group_rows ? (group_rows - first_row + row_stride - 1) / row_stride : 0;
   P.tlas_stack = ctx->tlas_stack; P.blas_stack = ctx->blas_stack + ctx->opt_stack_pad; P.watchdog_steps = ctx->watchdog_steps;
-  P.block_threads = ctx->opt_block_threads; P.xcd_run = ctx->opt_xcd_run; P.tile_order = ctx->opt_tile_order; P.refill_min = ctx->opt_refill_min; P.blas_min = ctx->opt_blas_min;
+  P.block_threads = ctx->opt_block_threads; P.xcd_run = ctx->opt_xcd_run; P.tile_order = ctx->opt_tile_order; P.refill_min = ctx->opt_refill_min;
+  // lanes parked at a triangle BVH before the traversal phase runs: 16 with one mesh (C3 -2 %, C3D -6 % against 28), 24 when rays walk
+  // several (C4, C5 -1 %) — re-measured after the work distribution became local (profiles/r02_logs/r2_blas_min.log)
+  P.blas_min = ctx->opt_blas_min > 0 ? ctx->opt_blas_min : (S.n_meshes > 1 ? 24 : 16);
   // the traversal phase yields when fewer lanes than this are still traversing: measured best 14-18 with one mesh, 8-11 when rays
   // walk several triangle BVHs per Trace() (a yielding lane then continues its object-level walk sooner)
   P.blas_exit = ctx->opt_blas_exit > 0 ? ctx->opt_blas_exit : (S.n_meshes > 1 ? 9 : 14); P.shade_min = ctx->opt_shade_min; P.sky_min = ctx->opt_sky_min;
@@ -1204,7 +1207,7 @@ int urt_set_option(urt_context* ctx, const char* name, int value) {
     set_blas_leaf_max(value);
     ctx->scene_dirty = true;
   } else if (std::strcmp(name, "blas_min") == 0) {
-    if (value < 1 || value > 256) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "blas_min must be in [1, 256] (kernel_mode 5 counts the waiting rays of a workgroup)");
+    if (value < 0 || value > 256) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "blas_min must be in [0, 256] (0 = auto; kernel_mode 5 counts the waiting rays of a workgroup)");
     ctx->opt_blas_min = value;
   } else if (std::strcmp(name, "blas_exit") == 0) {
     if (value < 0 || value > 64) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "blas_exit must be in [0, 64] (0 = auto)");
