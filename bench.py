@@ -72,6 +72,8 @@ def main():
     ap.add_argument("--config", default="C3", help="BASELINE.json config to trace (C2..C5, C3D = C3 in close-up); the metric is quoted on C3")
     ap.add_argument("--kernel-mode", type=int, default=None, help="0 per-pixel, 1 per-bounce queues, 2 persistent, 3 persistent + phase-scheduled lanes (default), 4 path pool in LDS, 5 shared traversal service")
     ap.add_argument("--frames-per-launch", type=int, default=None, help="library option frames_per_launch (0 auto, 1 = one launch per frame, 2..64)")
+    ap.add_argument("--gather-every", type=int, default=1, help="multi-GPU: gather the accumulated strips to rank 0 after every K-th frame (and after the last); "
+                    "1 = the frame-end gather of every frame (default); a gather overwrites the whole image, so K > 1 only lowers the rate at which rank 0 could present it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -166,9 +168,9 @@ def main():
 
     def submit():
         """Submit the deferred batch (trace launch + blends + packs) and run its gathers on the communication stream."""
+        ctx.flush()
         if not state["pending"]:
             return
-        ctx.flush()
         ev_batch.record(main_stream)
         with torch.cuda.stream(comm_stream):
             comm_stream.wait_event(ev_batch)
@@ -191,14 +193,25 @@ def main():
         if i >= ring:
             main_stream.wait_event(ev_gather[slot])                       # the gather that last used this pack buffer is done with it
         master.OnRenderImage()                                            # deferred: dispatch of this rank's strips + accumulate
-        master._converged.pack_rows(rank, world, packed[slot].data_ptr()) # deferred behind them
-        state["pending"].append(slot)
         state["i"] = i + 1
-        if len(state["pending"]) >= burst:
+        state["frames"] = state.get("frames", 0) + 1
+        if (i + 1) % max(1, args.gather_every) == 0:
+            master._converged.pack_rows(rank, world, packed[slot].data_ptr()) # deferred behind them
+            state["pending"].append(slot)
+            state["stale"] = False
+        else:
+            state["stale"] = True                                          # rank 0's image is behind: drain() gathers the last frame
+        if state["frames"] >= burst:
+            state["frames"] = 0
             submit()
 
     def drain():
         if world > 1:
+            if state.get("stale"):
+                slot = (state["i"] - 1) % ring
+                master._converged.pack_rows(rank, world, packed[slot].data_ptr())
+                state["pending"].append(slot)
+                state["stale"] = False
             submit()
             for e in ev_gather:
                 main_stream.wait_event(e)
@@ -332,7 +345,8 @@ def main():
                                    f"ground plane, equirect sky; numBounces {scene.num_bounces}, numRays {scene.num_rays}",
                        "frame": [width, height], "pixels_per_gpu": width * height // world,
                        "partition": (f"8-row strips round-robin over ranks, one gather per frame; {burst} frames per launch, each burst's gathers" + (" overlap the next burst's rendering" if overlap else " serialised")) if world > 1 else "single GPU",
-                       "rays_per_step": int(total_rays / args.steps), "kernel_mode": args.kernel_mode if args.kernel_mode is not None else 3},
+                       "rays_per_step": int(total_rays / args.steps), "kernel_mode": args.kernel_mode if args.kernel_mode is not None else 3,
+                       **({"gather_every": args.gather_every} if world > 1 else {})},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
