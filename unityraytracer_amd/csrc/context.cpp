@@ -474,6 +474,18 @@ int ensure_slab(urt_context* ctx, urt_handle h, Texture& t, int frames) {
   return URT_OK;
 }
 
+// Persistent kernels: a work-counter shard hands out RUNS of consecutive 8x8 tiles (and the waves of a workgroup share a shard),
+// so neighbours on the chip work on neighbouring tiles.  Run length when "xcd_run" is 0 (auto): the largest power of two <= 8 that
+// leaves every shard >= 256 runs per launch.  Measured with the frames of a launch interleaved (profiles/r02_logs/r2_run_by_launch.log, C3):
+// one frame per launch 0.62 ms at 1 vs 0.82 at 64 (few runs per shard: the shards run dry unevenly); 16 frames 0.24 vs 0.33;
+// 64 frames 0.221 at 4-8 vs 0.224 at 64.  (Before the interleaving, runs of 64 were the gain: r2_xcd_run.log.)
+int auto_run_length(const FrameParams& P, int n_frames) {
+  long runs = (long)P.tiles_x * P.n_strips * std::max(1, n_frames) / ((long)std::max(1, P.n_shards) * 256L);
+  int g = 1;
+  while (g < 8 && 2L * g <= runs) g *= 2;
+  return g;
+}
+
 // kernel_mode 3: what lives in the workgroup's LDS next to the stacks (fills P.top_nodes, P.lds_*, P.block_threads, P.list_base,
 // P.tlas_stack) and how FRONT treats MeshObjects (returns the front mode of kernels.h launch_sched)
 int configure_sched(urt_context* ctx, const DevScene& S, FrameParams& P, bool top_in_front) {
@@ -564,6 +576,7 @@ int flush_pending(urt_context* ctx) {
   FrameParams P = B.P;
   P.n_frames = n;
   P.frame_group = std::max(1, std::min(P.frame_group, n));
+  if (ctx->opt_xcd_run <= 0) P.xcd_run = auto_run_length(P, n);
   P.frame_stride = (unsigned int)ctx->slab_stride;
   int rc = launch_sched_frames(ctx, B.S, P, B.T, ctx->slab, B.front_mode, B.count);
   if (rc) return rc;
@@ -609,7 +622,7 @@ int batch_limit(urt_context* ctx, const FrameParams& P) {
     lim = (int)std::min<uint64_t>(kAutoFrames, std::max<uint64_t>(1, (8ull << 30) / std::max<uint64_t>(1, frame_bytes)));
   }
   // the work counter hands out 32-bit pixel slots: frames x tiles x 64 must stay below 2^32
-  uint64_t slots = std::max<uint64_t>(1, ((uint64_t)P.tiles_x * (uint64_t)P.n_strips + (uint64_t)std::max(1, P.xcd_run)) * 64u);   // (a frame's last run is padded when frames are interleaved)
+  uint64_t slots = std::max<uint64_t>(1, ((uint64_t)P.tiles_x * (uint64_t)P.n_strips + (uint64_t)std::max(64, ctx->opt_xcd_run)) * 64u);   // (a frame's last run is padded when frames are interleaved)
   lim = (int)std::min<uint64_t>((uint64_t)lim, std::max<uint64_t>(1, 0xfffffffeull / slots / 2));
   return std::max(1, std::min(lim, (int)kMaxFramesPerLaunch));
 }
@@ -665,16 +678,7 @@ int do_dispatch(urt_context* ctx, int kernel, int gx, int gy, int gz, int first_
   P.n_frames = 1; P.frame_stride = 0;
   if (P.n_strips == 0 || P.tiles_x == 0) return URT_OK;
   P.n_shards = ctx->opt_work_shards; P.frame_group = ctx->opt_frame_group;
-  if (ctx->opt_xcd_run <= 0) {
-    // persistent kernels: a work-counter shard hands out RUNS of consecutive 8x8 tiles, so a wave's successive refills are
-    // neighbours on the image (their rays meet the same BVH subtrees and sky lines) and an XCD's L2 serves a few bands of the
-    // frame.  The largest power of two that still leaves every shard >= 4 runs per frame, at most 64 (1080p and 2160p: 64) —
-    // measured against 1: C2 -9 %, C3 -4 %, C3D -7 %, C4 -2 %, C5 -4 %; odd lengths (63) lose most of it, runs of 256+ unbalance a
-    // 1080p frame (profiles/r02_logs/r2_xcd_run.log).
-    long tiles = (long)P.tiles_x * P.n_strips, g = 1;
-    while (g < 64 && 2 * g <= tiles / (long)(P.n_shards * 4)) g *= 2;
-    P.xcd_run = (ctx->opt_kernel_mode >= 2) ? (int)g : 1;
-  }
+  if (ctx->opt_xcd_run <= 0) P.xcd_run = ctx->opt_kernel_mode >= 2 ? auto_run_length(P, 1) : 1;   // (batched launches: again at submission, with the launch's frame count)
   if ((uint64_t)P.tiles_x * (uint64_t)P.n_strips * 64u >= 0xffffffffull)
     return fail(ctx, URT_ERR_INVALID_ARGUMENT, "Dispatch: too many pixel slots in one dispatch");
 
