@@ -47,7 +47,7 @@ class SplitMix64:
 
     def value(self) -> float:
         """Uniform in [0,1) with 24 bits — stands in for UnityEngine.Random.value (RM:777-778)."""
-        return float(np.float32((self.next_u64() >> 40) / float(1 << 24)))
+        return (self.next_u64() >> 40) / 16777216.0            # 24 bits / 2^24: exact in float32 (and in the double it is returned as)
 
     def uniform(self, lo: float, hi: float) -> float:
         return lo + (hi - lo) * self.value()

@@ -248,6 +248,7 @@ class ComputeShader:
 
     def __init__(self, ctx: Context):
         self.ctx = ctx
+        self._bound = ctx.__dict__.setdefault("_bound", {})   # what this context last received, per name (shared by every wrapper of the context)
 
     def FindKernel(self, name: str) -> int:
         if name != "CSMain":
@@ -256,37 +257,52 @@ class ComputeShader:
 
     # The reference re-sets every uniform and binding every frame (RM:772-795).  Setting a name to the value it already has is
     # a no-op at the boundary, so the wrapper remembers what this context last received per name and skips the call: the host
-    # loop of a frame drops from ~18 to ~8 us, which is GPU idle time before a batch of deferred frames is submitted.
-    def _set(self, key, val, call):
-        bound = self.ctx.__dict__.setdefault("_bound", {})
-        if bound.get(key) == val:
-            return
-        self.ctx.check(call())
-        bound[key] = val                                      # only what the library accepted
-
+    # loop of a frame drops from ~18 to ~9 us, which is GPU idle time before a batch of deferred frames is submitted.
     def SetMatrix(self, name: str, m16):
         a = np.ascontiguousarray(m16, dtype=np.float32).reshape(16)
-        self._set(("m", name), a.tobytes(), lambda: self.ctx.lib.urt_shader_set_matrix(self.ctx._h, name.encode(), a.ctypes.data_as(C.c_void_p)))
+        key, val = ("m", name), a.tobytes()
+        if self._bound.get(key) == val:
+            return
+        self.ctx.check(self.ctx.lib.urt_shader_set_matrix(self.ctx._h, name.encode(), a.ctypes.data_as(C.c_void_p)))
+        self._bound[key] = val                                 # only what the library accepted
 
     def SetVector(self, name: str, v):
         a = np.zeros(4, dtype=np.float32)
         v = np.asarray(v, dtype=np.float32).reshape(-1)
         a[: len(v)] = v
-        self._set(("v", name), a.tobytes(), lambda: self.ctx.lib.urt_shader_set_vector(self.ctx._h, name.encode(), a.ctypes.data_as(C.c_void_p)))
+        key, val = ("v", name), a.tobytes()
+        if self._bound.get(key) == val:
+            return
+        self.ctx.check(self.ctx.lib.urt_shader_set_vector(self.ctx._h, name.encode(), a.ctypes.data_as(C.c_void_p)))
+        self._bound[key] = val
 
     def SetFloat(self, name: str, v: float):
-        self._set(("f", name), np.float32(v).tobytes(), lambda: self.ctx.lib.urt_shader_set_float(self.ctx._h, name.encode(), float(v)))
+        key, val = ("f", name), C.c_float(v).value             # the float32 the library will see
+        if self._bound.get(key) == val and val == val:
+            return
+        self.ctx.check(self.ctx.lib.urt_shader_set_float(self.ctx._h, name.encode(), float(v)))
+        self._bound[key] = val
 
     def SetInt(self, name: str, v: int):
-        self._set(("i", name), int(v), lambda: self.ctx.lib.urt_shader_set_int(self.ctx._h, name.encode(), int(v)))
+        key, val = ("i", name), int(v)
+        if self._bound.get(key) == val:
+            return
+        self.ctx.check(self.ctx.lib.urt_shader_set_int(self.ctx._h, name.encode(), val))
+        self._bound[key] = val
 
     def SetTexture(self, kernel: int, name: str, tex: RenderTexture | None):
-        h = tex.handle if tex else 0
-        self._set(("t", kernel, name), h, lambda: self.ctx.lib.urt_shader_set_texture(self.ctx._h, kernel, name.encode(), h))
+        key, h = ("t", kernel, name), tex.handle if tex else 0
+        if self._bound.get(key) == h:
+            return
+        self.ctx.check(self.ctx.lib.urt_shader_set_texture(self.ctx._h, kernel, name.encode(), h))
+        self._bound[key] = h
 
     def SetBuffer(self, kernel: int, name: str, buf: ComputeBuffer | None):
-        h = buf.handle if buf else 0
-        self._set(("b", kernel, name), h, lambda: self.ctx.lib.urt_shader_set_buffer(self.ctx._h, kernel, name.encode(), h))
+        key, h = ("b", kernel, name), buf.handle if buf else 0
+        if self._bound.get(key) == h:
+            return
+        self.ctx.check(self.ctx.lib.urt_shader_set_buffer(self.ctx._h, kernel, name.encode(), h))
+        self._bound[key] = h
 
     def Dispatch(self, kernel: int, groups_x: int, groups_y: int, groups_z: int):
         self.ctx.check(self.ctx.lib.urt_shader_dispatch(self.ctx._h, kernel, groups_x, groups_y, groups_z))
