@@ -7,8 +7,8 @@
 
 Metric (BASELINE.json): Mrays/sec @1920x1080, 8 bounces.  A *ray* is one Trace() invocation
 (RayTraceShader.compute:454), counted by the kernels themselves; a *step* is one frame of the reference's
-frame protocol (RayTraceMaster.OnRenderImage: set uniforms -> Dispatch -> AdditionShader blit), with
-every input already resident in HBM.  Workload at N=1: config C3 of BASELINE.json (bunny-class 69,600-triangle
+frame protocol (RayTraceMaster.OnRenderImage: set uniforms -> Dispatch -> AdditionShader blit -> present blit to
+`destination`, RM:806-820), with every input already resident in HBM.  Workload at N=1: config C3 of BASELINE.json (bunny-class 69,600-triangle
 mesh + triangle BVH, 1920x1080, numBounces 8, numRays 1, synthetic scene from unityraytracer_amd.scenes).
 
 Multi-GPU (weak scaling): one process per GPU; the frame grows to N x (1920x1080) pixels at the same
@@ -77,13 +77,22 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` as issued by hand or by a driver that does not wrap it in torch.distributed.run: this process
+        # has made no GPU call yet (torch is not even imported), so it may start the N ranks itself — as a CHILD process, never
+        # an exec — forward rank 0's JSON line (the child's stdout is inherited) and exit with the launcher's code.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd).returncode)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-        args.gpus = world
+    args.gpus = world
 
     import torch
     import torch.distributed as dist
@@ -153,6 +162,14 @@ def main():
         if rank == 0:
             from unityraytracer_amd import RenderTexture
             full = RenderTexture(ctx, width, height)
+    # The step is the reference's LITERAL frame (RM:806-820): Dispatch -> Blit(_target, _converged, additionMaterial) ->
+    # Blit(_converged, destination).  N = 1: `destination` is a RenderTexture the frame is presented to every step (the library
+    # queues the present with the deferred frames and fuses it into the blend pass).  N > 1: the presented image is `full` on
+    # rank 0 — the gather's de-interleave writes it every frame, that IS the present of the gathered frame.
+    destination = None
+    if world == 1:
+        from unityraytracer_amd import RenderTexture
+        destination = RenderTexture(ctx, width, height)
     state = {"i": 0, "pending": []}
 
     def do_gather(slot):
@@ -186,7 +203,7 @@ def main():
 
     def step():
         if world == 1:
-            master.OnRenderImage()
+            master.OnRenderImage(destination)
             return
         i = state["i"]
         slot = i % ring
@@ -258,7 +275,7 @@ def main():
         master._frame = args.warmup
         ctx.reset_counters()
         for _ in range(args.steps):
-            master.OnRenderImage()
+            master.OnRenderImage(destination)
         cc = ctx.counters()
         ctx.set_option("count_stats", 0)
         assert cc["rays"] == c["rays"], "counting replay traced a different number of rays"
@@ -341,6 +358,7 @@ def main():
             "metric": "Mrays/sec @1920x1080, 8 bounces", "value": round(total_rays / elapsed / 1e6, 2), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "present": True,     # the step includes RM:819's Graphics.Blit(_converged, destination) (N > 1: the gather into rank 0's image)
             "config": {"workload": f"{args.config}: {scene.name}, {scene.n_triangles} triangles + triangle BVH, {len(scene.spheres)} spheres, "
                                    f"ground plane, equirect sky; numBounces {scene.num_bounces}, numRays {scene.num_rays}",
                        "frame": [width, height], "pixels_per_gpu": width * height // world,
@@ -351,6 +369,8 @@ def main():
         }
         print(json.dumps(out), flush=True)
     master.OnDisable()
+    if destination is not None:
+        destination.Release()
     ctx.close()
     if world > 1:
         dist.destroy_process_group()

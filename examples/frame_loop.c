@@ -94,11 +94,12 @@ int main(int argc, char** argv) {
       float* p = sky + 4 * (y * SW + x);
       p[0] = 0.3f + 0.5f * t; p[1] = 0.4f + 0.5f * t; p[2] = 0.6f + 0.4f * t; p[3] = 1.0f;
     }
-  urt_handle sky_tex, target, converged;
+  urt_handle sky_tex, target, converged, destination;
   CHECK(ctx, urt_texture_create(ctx, SW, SH, &sky_tex));
   CHECK(ctx, urt_texture_set_pixels(ctx, sky_tex, sky));
   CHECK(ctx, urt_texture_create(ctx, W, H, &target));                                      /* InitRenderTexture, RM:824-845 */
   CHECK(ctx, urt_texture_create(ctx, W, H, &converged));
+  CHECK(ctx, urt_texture_create(ctx, W, H, &destination));                                 /* OnRenderImage's `destination` (RM:848) */
 
   /* camera of Scene1 (position (0,1,-10), identity rotation, vertical fov 81 degrees): Unity's GL-convention matrices */
   float c2w[16] = {1, 0, 0, 0,  0, 1, 0, 0,  0, 0, -1, 0,  0, 1, -10, 1};                 /* TR * diag(1,1,-1), column-major */
@@ -125,10 +126,11 @@ int main(int argc, char** argv) {
     /* ---- Render (RM:798-821) ---- */
     CHECK(ctx, urt_shader_set_texture(ctx, 0, "Result", target));
     CHECK(ctx, urt_shader_dispatch(ctx, 0, (W + 7) / 8, (H + 7) / 8, 1));
-    CHECK(ctx, urt_blit_add(ctx, target, converged, (float)frame));                         /* _Sample = _currentSample, then ++ */
+    CHECK(ctx, urt_blit_add(ctx, target, converged, (float)frame));                         /* RM:817-818: _Sample = _currentSample */
+    CHECK(ctx, urt_blit(ctx, converged, destination));                                      /* RM:819: present; then _currentSample++ */
   }
   static float image[W * H * 4];
-  CHECK(ctx, urt_texture_get_pixels(ctx, converged, image));                                /* submits the batched frames and waits */
+  CHECK(ctx, urt_texture_get_pixels(ctx, destination, image));                              /* submits the batched frames (all of them: the presents were queued too) and waits */
   urt_counters c;
   CHECK(ctx, urt_get_counters(ctx, &c));
   char path[1024];
@@ -145,6 +147,7 @@ int main(int argc, char** argv) {
   for (int k = 0; k < 7; k++) CHECK(ctx, urt_buffer_release(ctx, handles[k]));
   CHECK(ctx, urt_texture_release(ctx, target));
   CHECK(ctx, urt_texture_release(ctx, converged));
+  CHECK(ctx, urt_texture_release(ctx, destination));
   CHECK(ctx, urt_texture_release(ctx, sky_tex));
   urt_context_destroy(ctx);
   return 0;

@@ -44,7 +44,9 @@ enum {
   URT_ERR_UNBOUND = 5,        /* dispatch without a Result texture / camera matrices */
   URT_ERR_LAYOUT = 6,         /* stride/count does not match the layout the name requires */
   URT_ERR_OUT_OF_MEMORY = 7,
-  URT_ERR_SCENE = 8           /* scene data fails validation (index out of range, stack too deep) */
+  URT_ERR_SCENE = 8,          /* scene data fails validation (index out of range, stack too deep) */
+  URT_ERR_WATCHDOG = 9        /* waves of a trace launch left through the kernel's iteration cap: pixels are missing.  Reported
+                                 once, by the first urt_synchronize / urt_texture_get_pixels after the launch completed */
 };
 
 /* ---- library / context ------------------------------------------------------------------- */
@@ -60,10 +62,16 @@ URT_API int urt_context_set_stream(urt_context* ctx, void* hip_stream);
 /* Block until everything issued so far is complete. */
 URT_API int urt_synchronize(urt_context* ctx);
 /* Frame batching.  On its own stream the library DEFERS urt_shader_dispatch (default kernel) and the urt_blit_add /
- * urt_texture_pack_rows calls that follow it, and traces several consecutive frames with one persistent launch (a 1080p
- * frame is too small to fill 256 CUs through its 8-bounce tail; "frames_per_launch" below).  Every call that could observe
- * an image (readback, synchronize, counters, Blit to another image, SetPixels, release, option changes, ...) submits the
- * deferred work first, so results and ordering are exactly those of immediate execution (RM:806-820 is in-order).
+ * urt_blit / urt_texture_pack_rows calls that follow it, and traces several consecutive frames with one persistent launch
+ * (a 1080p frame is too small to fill 256 CUs through its 8-bounce tail; "frames_per_launch" below).  The whole frame of
+ * RM:806-820 — Dispatch, Blit(_target, _converged, mat), Blit(_converged, destination) — is deferred; the blends of a batch
+ * and the present run as ONE pass after the launch.  Every call that could observe an image (readback, synchronize,
+ * counters, SetPixels, release, a device pointer handed out, option changes, ...) submits the deferred work first, so
+ * results and ordering are exactly those of immediate execution (RM:806-820 is in-order).
+ * As-if rule for the present: a deferred urt_blit(src, dst) that is followed by another deferred urt_blit to the same dst,
+ * with nothing that could observe dst in between, is not materialised — dst receives the later image only.  No observer
+ * can tell (observers submit first); a caller that looks at dst's memory by its own means must call urt_flush /
+ * urt_synchronize first, as for any deferred work.
  * An error of deferred work (a failing launch) is reported by the call that submits it.
  * urt_flush submits the deferred work to the stream without waiting — for callers that synchronise by their own means
  * (their own stream + events); with a caller-owned stream deferral is off unless "frames_per_launch" is set explicitly. */
@@ -126,7 +134,8 @@ URT_API int urt_shader_dispatch_rows(urt_context* ctx, int kernel, int groups_x,
 /* _additionMaterial.SetFloat("_Sample", sample); Graphics.Blit(src, dst, _additionMaterial):
  * dst = src * a + dst * (1 - a) with a = 1 / (sample + 1), all four channels   RM:817-818, AS:9,39-41 */
 URT_API int urt_blit_add(urt_context* ctx, urt_handle src, urt_handle dst, float sample);
-/* Graphics.Blit(src, dst): copy                                      RM:819 */
+/* Graphics.Blit(src, dst): copy — the present of the accumulated frame      RM:819
+ * While frames are deferred the copy is queued behind them (see "Frame batching" above). */
 URT_API int urt_blit(urt_context* ctx, urt_handle src, urt_handle dst);
 /* Strip helpers for the frame-end gather: copy the 8-row strips first_group_row, +row_stride, ... of
  * an image to/from a dense device buffer (strip-major).  out_bytes reports the packed size. */
@@ -154,7 +163,8 @@ typedef struct urt_counters {
   uint64_t pixels;        /* pixels written (16 B each) */
   uint64_t dispatches;    /* urt_shader_dispatch* calls since reset */
   float trace_ms;         /* GPU time of the trace kernels of those dispatches (HIP events; needs "time_dispatch") */
-  uint32_t watchdog_trips; /* waves that hit a persistent kernel's iteration cap: always 0 unless there is a bug */
+  uint32_t watchdog_trips; /* waves that hit a persistent kernel's iteration cap (scaled with frames x rays x bounces of the launch): 0 unless
+                              there is a bug; when not, the next urt_synchronize / urt_texture_get_pixels fails with URT_ERR_WATCHDOG */
   uint64_t launches;      /* trace-kernel launches those dispatches became (< dispatches when frames were batched) */
 } urt_counters;
 /* Options: "blas_builder" (0 = binned-SAH triangle BVH built on host threads, the default: best trees; 1 = LBVH built on the GPU
@@ -181,7 +191,9 @@ typedef struct urt_counters {
  *          mode 4: "pool_k" (1..4), "pool_refill", "pool_blas_min" (1..256), "pool_blas_exit", "pool_inloop",
  *                  "pool_other_min" (1..64),
  *          "blas_leaf_max" (1..8: triangles per BVH leaf; rebuilds the BVH),
- *          "stack_pad" (0..96: test hook, unused extra entries per traversal stack -> the > 64 KiB LDS launch path)
+ *          "stack_pad" (0..96: test hook, unused extra entries per traversal stack -> the > 64 KiB LDS launch path),
+ *          "watchdog_cap" (test hook: scheduler trips a wave may make before it gives up; 0 = auto = 2^24 x frames of the launch x
+ *                          max(1, numRays x numBounces / 8))
  *          — tuning knobs; they change speed only, never pixels. */
 URT_API int urt_set_option(urt_context* ctx, const char* name, int value);
 URT_API int urt_get_counters(urt_context* ctx, urt_counters* out);   /* synchronises */

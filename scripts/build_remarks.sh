@@ -3,9 +3,15 @@
 # (VGPRs / AGPRs / SGPRs / scratch / occupancy / LDS).  Usage: scripts/build_remarks.sh [out.so] [extra hipcc flags...]
 cd "$(dirname "$0")/../unityraytracer_amd" || exit 1
 OUT=${1:-/tmp/urt_remarks.so}; shift
+# KERNELS_ONLY=1: compile csrc/kernels.hip alone (-c): the trace kernels' numbers in half a minute
+if [ -n "$KERNELS_ONLY" ]; then
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -fvisibility=hidden -pthread -Xarch_host -march=x86-64-v3 \
+    -Wall -Wno-unused-function -Rpass-analysis=kernel-resource-usage "$@" -c csrc/kernels.hip -o "$OUT" 2> /tmp/urt_remarks.log
+else
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -fvisibility=hidden -pthread -Xarch_host -march=x86-64-v3 \
   -Wall -Wno-unused-function -Rpass-analysis=kernel-resource-usage "$@" -o "$OUT" \
   csrc/kernels.hip csrc/lbvh.hip csrc/context.cpp csrc/blas_builder.cpp csrc/host_scene.cpp csrc/host_io.cpp csrc/host_debug.cpp csrc/group.cpp 2> /tmp/urt_remarks.log
+fi
 rc=$?
 grep -E "error" -A6 /tmp/urt_remarks.log | head -40
 python3 - <<'PY'

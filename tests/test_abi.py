@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol(built_library):
     lib = C.CDLL(built_library)
     for name in header_symbols():
         assert hasattr(lib, name), f"{name} is declared in include/urt.h but not exported"
-    assert _lib.load().urt_abi_version() == 2
+    assert _lib.load().urt_abi_version() == 3
 
 
 def test_layout_strides_match_reference():

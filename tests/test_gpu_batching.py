@@ -192,3 +192,130 @@ def test_checkpoint_resume_of_progressive_accumulation(gpu_ctx, tmp_path):
     got = m2._converged.GetPixels()
     m2.OnDisable()
     assert bits_equal(got, ref_conv)
+
+
+def test_present_blit_is_deferred_and_invisible(gpu_ctx):
+    """The reference's literal frame — Dispatch, Blit(_target, _converged, mat), Blit(_converged, destination), RM:810-820 —
+    keeps batching: the present is queued behind the deferred frames and fused into the blend pass.  `destination` read in the
+    middle of a batch, after a batch boundary and at the end equals one launch per frame and the oracle's running mean; a second
+    destination that is presented to only now and then (an earlier present elided under the as-if rule, a run that ends on a
+    blend) sees exactly the frame it was last presented with."""
+    sc = scenes.mixed_test_scene(136, 88)
+    n = 13
+
+    def protocol(fpl, peek_at):
+        gpu_ctx.set_option("kernel_mode", 3)
+        gpu_ctx.set_option("frames_per_launch", fpl)
+        gpu_ctx.reset_counters()
+        m = RayTraceMaster(gpu_ctx, sc)
+        dest = RenderTexture(gpu_ctx, sc.width, sc.height)
+        other = RenderTexture(gpu_ctx, sc.width, sc.height)
+        peeks = {}
+        for i in range(n):
+            m.OnRenderImage(dest)
+            if i in (3, 4, 9):
+                Graphics.Blit(m._converged, other)             # a second present target, written three times
+            if i in peek_at:
+                peeks[i] = dest.GetPixels()
+        out = (dest.GetPixels(), other.GetPixels(), m._converged.GetPixels(), peeks)
+        c = gpu_ctx.counters()
+        dest.Release(); other.Release(); m.OnDisable()
+        gpu_ctx.set_option("frames_per_launch", 0)
+        return out, c
+
+    ref, c1 = protocol(1, (2, 7))
+    assert c1["launches"] == n
+    assert bits_equal(ref[0], ref[2])                          # destination == _converged after the last frame
+    for fpl in (4, 5, 16, 0):
+        got, c = protocol(fpl, (2, 7))
+        assert bits_equal(got[0], ref[0]) and bits_equal(got[1], ref[1]) and bits_equal(got[2], ref[2]), fpl
+        for i in ref[3]:
+            assert bits_equal(got[3][i], ref[3][i]), (fpl, i)
+        assert c["launches"] < n and c["rays"] == c1["rays"] and c["watchdog_trips"] == 0, (fpl, c)
+    # without observers the 13 presented frames share launches as if nothing were presented (64 per launch by default)
+    got, c = protocol(0, ())
+    assert c["launches"] == 1 and bits_equal(got[0], ref[0]) and bits_equal(got[1], ref[1])
+    # the oracle's running mean after frame 9 is what `other` shows, after frame 12 what `destination` shows
+    o = pyoracle.Oracle(sc)
+    nodes, tri, root, _, _ = debug_build_blas(sc.mesh_objects, sc.vertices, sc.indices)
+    o.set_blas(nodes, tri, root)
+    acc = None
+    for i in range(n):
+        ox, oy, sd = scenes.frame_uniforms(i)
+        o.set_frame((ox, oy), sd)
+        img = o.render(mode=1, threads=8)
+        acc = pyoracle.accumulate(img, acc if acc is not None else np.zeros_like(img), i)
+        if i == 9:
+            assert bits_equal(ref[1], acc)
+    assert bits_equal(ref[0], acc)
+
+
+def test_present_of_the_result_and_into_odd_targets(gpu_ctx):
+    """Deferred plain blits that are NOT the present pattern: a copy of the Result itself (a slab slot), a copy between two
+    unrelated images, a copy whose destination is the sky (must not be deferred: the deferred launch reads the sky)."""
+    sc = scenes.mixed_test_scene(96, 64)
+
+    def protocol(fpl):
+        gpu_ctx.set_option("frames_per_launch", fpl)
+        m = RayTraceMaster(gpu_ctx, sc)
+        a = RenderTexture(gpu_ctx, sc.width, sc.height)
+        b = RenderTexture(gpu_ctx, sc.width, sc.height)
+        half = RenderTexture(gpu_ctx, sc.sky.shape[1], sc.sky.shape[0])
+        half.SetPixels(sc.sky * np.float32(0.5))
+        for i in range(6):
+            m.OnRenderImage()
+            if i == 1:
+                Graphics.Blit(m._target, a)                    # frame 1's Result
+                Graphics.Blit(a, b)                            # chained: reads what the deferred copy above wrote
+            if i == 3:
+                Graphics.Blit(half, m.SkyboxTexture)           # frames 4, 5 see the darker sky, frames 0..3 the old one
+        out = (a.GetPixels(), b.GetPixels(), m._converged.GetPixels())
+        a.Release(); b.Release(); half.Release(); m.OnDisable()
+        gpu_ctx.set_option("frames_per_launch", 0)
+        return out
+
+    ref = protocol(1)
+    assert bits_equal(ref[0], ref[1])
+    for fpl in (4, 0):
+        got = protocol(fpl)
+        for x, y in zip(got, ref):
+            assert bits_equal(x, y), fpl
+
+
+def test_watchdog_trip_is_an_error_not_a_silent_hole(gpu_ctx):
+    """A wave that leaves the persistent kernel through its iteration cap has not written its pixels.  With the cap forced
+    absurdly low ("watchdog_cap", a test hook) the launch ends early: the next synchronising call must fail with
+    URT_ERR_WATCHDOG, the counter must show the trips, and the context must be usable afterwards."""
+    from unityraytracer_amd import UrtError
+    sc = scenes.mixed_test_scene(160, 96)
+    gpu_ctx.set_option("kernel_mode", 3)
+    gpu_ctx.reset_counters()
+    m = RayTraceMaster(gpu_ctx, sc)
+    m.OnRenderImage()
+    good = m._target.GetPixels()
+    try:
+        gpu_ctx.set_option("watchdog_cap", 3)
+        m.OnRenderImage(); m.OnRenderImage()                   # deferred: nothing has run yet
+        with pytest.raises(UrtError) as ei:
+            m._target.GetPixels()                              # submits, waits, and must refuse the incomplete image
+        assert ei.value.code == 9 and "cap" in str(ei.value)
+        assert gpu_ctx.counters()["watchdog_trips"] > 0
+        gpu_ctx.synchronize()                                  # reported once
+    finally:
+        gpu_ctx.set_option("watchdog_cap", 0)
+    gpu_ctx.reset_counters()
+    m2 = RayTraceMaster(gpu_ctx, sc)
+    m2.OnRenderImage()
+    again = m2._target.GetPixels()
+    assert gpu_ctx.counters()["watchdog_trips"] == 0
+    m.OnDisable(); m2.OnDisable()
+    assert bits_equal(again, good)
+    # the automatic cap grows with the launch: 64 frames x 25 rays x 10 bounces must not trip (SampleScene's settings)
+    sc2 = scenes.mixed_test_scene(48, 32)
+    sc2.num_rays, sc2.num_bounces = 25, 10
+    m3 = RayTraceMaster(gpu_ctx, sc2)
+    for _ in range(8):
+        m3.OnRenderImage()
+    gpu_ctx.synchronize()
+    assert gpu_ctx.counters()["watchdog_trips"] == 0
+    m3.OnDisable()

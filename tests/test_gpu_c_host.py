@@ -62,6 +62,7 @@ def test_c99_host_matches_python_host(gpu_ctx, tmp_path):
     r = subprocess.run([exe, str(frames), out], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert f"{frames} frames of 160x96" in r.stdout and "watchdog 0" in r.stdout
+    assert f"in 1 launches ({frames} dispatches)" in r.stdout, r.stdout    # the per-frame present (RM:819) did not break the batch
     got = np.fromfile(out + ".rgba32f", dtype=np.float32).reshape(96, 160, 4)
     sc = c_example_scene()
     m = RayTraceMaster(gpu_ctx, sc)

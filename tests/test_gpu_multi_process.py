@@ -54,3 +54,72 @@ def test_two_processes_on_one_card_gather_equals_single_context(gpu_ctx, tmp_pat
     m.OnDisable()
     got = np.load(out)
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.timeout(900)
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2 ...` with no launcher around it (the shape of the driver's command): bench.py must start the
+    two ranks itself, run the multi-GPU step (strips, local accumulation, pack, one gather per frame, de-interleave) and print
+    ONE JSON line.  Two ranks share this box's card; the collective runs over gloo (URT_DIST_BACKEND) and rank 0 verifies the
+    gathered image against a single-rank render bit for bit (URT_BENCH_VERIFY)."""
+    import json
+    import subprocess
+    env = dict(os.environ, URT_DIST_BACKEND="gloo", URT_BENCH_VERIFY="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--config", "C2",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "[verify] gathered 2-rank frame == single-rank frame: True" in r.stderr, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 4 and j["value"] > 0 and j["present"] is True
+
+
+def _nccl_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from unityraytracer_amd import Context, RayTraceMaster, RenderTexture, scenes, strips
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, device_id=dev)
+    sc = scenes.mixed_test_scene(136, 100)
+    st = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(st)
+    with Context(0) as ctx:
+        ctx.set_stream(st.cuda_stream)
+        m = RayTraceMaster(ctx, sc, rank=rank, world_size=world)
+        m.OnRenderImage()
+        n_floats = strips.packed_rows(sc.height, world) * sc.width * 4
+        mine = torch.zeros(n_floats, dtype=torch.float32, device=dev)
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        m._converged.pack_rows(rank, world, mine.data_ptr())
+        ctx.flush()
+        dist.gather(mine, parts, dst=0)                       # RCCL, on the stream the pack kernel ran on
+        full = RenderTexture(ctx, sc.width, sc.height)
+        for r in range(world):
+            full.unpack_rows(r, world, parts[r].data_ptr())
+        np.save(out_path, full.GetPixels())
+        full.Release(); m.OnDisable()
+        ctx.set_stream(None)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_one_rank_nccl_gather_smoke(gpu_ctx, tmp_path):
+    """The RCCL calls of the multi-GPU step (init_process_group("nccl"), dist.gather of the packed strips on the render
+    stream) executed once on this one-GPU box: world_size 1, so no xGMI traffic — but the same library, stream hand-over
+    (urt_context_set_stream), pack -> gather -> unpack order and buffers as an N-rank run."""
+    import torch.multiprocessing as mp
+    from unityraytracer_amd import RayTraceMaster, scenes
+    out = str(tmp_path / "nccl.npy")
+    mp.spawn(_nccl_worker, args=(1, _free_port(), out), nprocs=1, join=True)
+    sc = scenes.mixed_test_scene(136, 100)
+    m = RayTraceMaster(gpu_ctx, sc)
+    m.OnRenderImage()
+    want = m._converged.GetPixels()
+    m.OnDisable()
+    assert np.array_equal(np.load(out).view(np.uint32), want.view(np.uint32))

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("URT_LIB_PATH") or os.path.join(_HERE, "libunityraytracer_amd.so")   # override: A/B builds in experiments
 
 URT_OK = 0
-ERROR_NAMES = {1: "INVALID_ARGUMENT", 2: "INVALID_HANDLE", 3: "NO_DEVICE", 4: "HIP", 5: "UNBOUND", 6: "LAYOUT", 7: "OUT_OF_MEMORY", 8: "SCENE"}
+ERROR_NAMES = {1: "INVALID_ARGUMENT", 2: "INVALID_HANDLE", 3: "NO_DEVICE", 4: "HIP", 5: "UNBOUND", 6: "LAYOUT", 7: "OUT_OF_MEMORY", 8: "SCENE", 9: "WATCHDOG"}
 
 # every symbol include/urt.h declares (tests check that the .so exports each of them)
 ABI_SYMBOLS = [

@@ -28,17 +28,34 @@ def _newer(target: str, deps) -> bool:
 
 
 def build_library(force: bool = False, verbose: bool = False) -> str:
-    """hipcc --offload-arch=gfx950 ... -> unityraytracer_amd/libunityraytracer_amd.so (cross-compiles without a GPU)."""
+    """hipcc --offload-arch=gfx950 ... -> unityraytracer_amd/libunityraytracer_amd.so (cross-compiles without a GPU).
+    One object per source under unityraytracer_amd/build/ (compiled in parallel, reused while newer than its source and every
+    header), then one link: an edit of context.cpp does not recompile the kernels."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")] + \
+    hdrs = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")] + \
         [os.path.join(_ROOT, "include", h) for h in os.listdir(os.path.join(_ROOT, "include"))]
-    if not force and _newer(LIB, deps):
+    if not force and _newer(LIB, srcs + hdrs):
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB] + srcs
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True, cwd=_HERE)
+    objdir = os.path.join(_HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    cflags = [f for f in HIPCC_FLAGS if f != "-shared"]
+    jobs = []
+    for src in srcs:
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        if force or not _newer(obj, [src] + hdrs + [os.path.abspath(__file__)]):
+            jobs.append([hipcc] + cflags + ["-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True, cwd=_HERE)
+
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+        list(ex.map(run, jobs))
+    objs = [os.path.join(objdir, os.path.basename(src) + ".o") for src in srcs]
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fvisibility=hidden", "-pthread", "-o", LIB] + objs)
     return LIB
 
 

@@ -137,7 +137,7 @@ struct urt_context {
   int scene_max_depth = 0;
   int opt_frames_per_launch = 0;            // 0 = auto (own stream: 64 frames per launch, fewer when the Result slots would exceed 8 GiB; caller's stream: 1), 1 = off, 2..64
   uint64_t scene_epoch = 0;                 // bumps at every scene preparation
-  struct PostOp { int kind; int frame; urt_handle tex; urt_handle dst; float sample; int first_row, row_stride; void* dense; };   // kind 0 = blit_add(tex@frame -> dst), 1 = pack_rows(tex -> dense)
+  struct PostOp { int kind; int frame; urt_handle tex; urt_handle dst; float sample; int first_row, row_stride; void* dense; };   // kind 0 = blit_add(tex@frame -> dst), 1 = pack_rows(tex -> dense), 2 = blit(tex -> dst), the present of RM:819
   struct Pending {
     int n = 0, limit = 1;
     urt_handle tex = 0;                     // the Result texture of the batch
@@ -155,6 +155,13 @@ struct urt_context {
   std::vector<hipEvent_t> event_pool;       // recycled timing events
   hipEvent_t ev_switch = nullptr;           // orders the old stream before the new one in urt_context_set_stream
   uint64_t launches = 0;                    // trace-kernel launches (a batched launch counts once)
+  // a wave that left a persistent kernel through one of its caps has not written its pixels: the kernels raise this host-mapped
+  // word (kernels.hip report_watchdog) and the next synchronising call fails with URT_ERR_WATCHDOG
+  unsigned int* h_trip_flag = nullptr;      // pinned, device-visible
+  unsigned int* d_trip_flag = nullptr;      // its device address
+  int opt_watchdog_cap = 0;                 // test hook: scheduler trips per wave (0 = auto, scaled with the launch)
+  int slab_frames_max = 0;                  // largest batch the Result slab could be allocated for (after out-of-memory retries)
+  size_t slab_oom_stride = 0;               // image size (pixels) for which not even two slots could be allocated
 };
 
 namespace {
@@ -177,6 +184,24 @@ int fail(urt_context* ctx, int code, const std::string& msg) {
   } catch (const std::bad_alloc&) { return fail(ctx, URT_ERR_OUT_OF_MEMORY, "host allocation failed"); } \
   catch (const std::exception& ex) { return fail(ctx, URT_ERR_INVALID_ARGUMENT, ex.what()); }        \
   catch (...) { return fail(ctx, URT_ERR_INVALID_ARGUMENT, "unknown exception"); }
+
+// Scheduler trips a wave of a persistent kernel may make before it gives up (kernels.hip).  A frame needs 1e3-1e5; the cap
+// grows with what the launch carries: frames x (rays x bounces / 8).
+unsigned int sched_trip_cap(urt_context* ctx, const FrameParams& P, int n_frames) {
+  if (ctx->opt_watchdog_cap > 0) return (unsigned int)ctx->opt_watchdog_cap;
+  uint64_t per = std::max<uint64_t>(1, (uint64_t)std::max(1, P.num_rays) * (uint64_t)std::max(1, P.num_bounces) / 8u);
+  uint64_t cap = (1ull << 24) * (uint64_t)std::max(1, n_frames) * per;
+  return (unsigned int)std::min<uint64_t>(cap, 0xfffffff0ull);
+}
+
+// After the stream has been waited for: did a wave of the work just completed leave through a cap?
+int check_watchdog(urt_context* ctx) {
+  if (!ctx->h_trip_flag) return URT_OK;
+  unsigned int n = __atomic_exchange_n(ctx->h_trip_flag, 0u, __ATOMIC_ACQ_REL);
+  if (n == 0) return URT_OK;
+  return fail(ctx, URT_ERR_WATCHDOG, std::to_string(n) + " wave(s) of a trace launch hit the kernel's iteration cap and left pixels unwritten "
+                                     "(urt_counters.watchdog_trips): the images written since the last successful synchronisation are incomplete");
+}
 
 void free_scene(urt_context* ctx) {
   if (!ctx->scene_allocs.empty()) (void)hipStreamSynchronize(ctx->stream);   // queued kernels may still read them
@@ -452,6 +477,7 @@ int detach_from_slab(urt_context* ctx, Texture& t) {
 int ensure_slab(urt_context* ctx, urt_handle h, Texture& t, int frames) {
   size_t stride = (size_t)t.w * (size_t)t.h;
   if (ctx->slab && ctx->slab_tex == h && ctx->slab_stride == stride && ctx->slab_frames >= frames) return URT_OK;
+  if (!ctx->slab && ctx->slab_oom_stride == stride) return URT_OK;   // two slots of this size did not fit last time: not tried per frame
   if (ctx->slab_tex) {                                   // somebody's current contents may live in the old slab
     auto it = ctx->textures.find(ctx->slab_tex);
     if (it != ctx->textures.end()) { int rc = detach_from_slab(ctx, it->second); if (rc) return rc; }
@@ -463,12 +489,25 @@ int ensure_slab(urt_context* ctx, urt_handle h, Texture& t, int frames) {
       (void)hipFree(ctx->slab);
       ctx->slab = nullptr; ctx->slab_frames = 0; ctx->slab_stride = 0;
     }
-    URT_HIP(ctx, hipMalloc((void**)&ctx->slab, stride * (size_t)frames * sizeof(float4)));
+    // out of memory (several contexts on one card, a huge image): halve the batch until the slots fit; one frame = no slab at
+    // all (the caller then renders unbatched, straight into the texture)
+    hipError_t e = hipErrorOutOfMemory;
+    while (frames >= 2) {
+      e = hipMalloc((void**)&ctx->slab, stride * (size_t)frames * sizeof(float4));
+      if (e != hipErrorOutOfMemory) break;
+      (void)hipGetLastError();
+      ctx->slab = nullptr;
+      frames /= 2;
+    }
+    if (e == hipErrorOutOfMemory) { ctx->slab = nullptr; ctx->slab_frames = 0; ctx->slab_stride = 0; ctx->slab_frames_max = 1; ctx->slab_oom_stride = stride; return URT_OK; }
+    URT_HIP(ctx, e);
     ctx->slab_frames = frames;
+    ctx->slab_frames_max = frames;
   } else {
     ctx->slab_frames = (int)(ctx->slab_stride * (size_t)ctx->slab_frames / stride);    // same bytes, re-cut for this image size
   }
   ctx->slab_stride = stride;
+  if (ctx->slab_frames < 2) return URT_OK;               // (re-cut for a larger image: no room for two slots -> unbatched)
   URT_HIP(ctx, hipMemsetAsync(ctx->slab, 0, stride * (size_t)ctx->slab_frames * sizeof(float4), ctx->stream));   // a new RenderTexture is zero-filled
   ctx->slab_tex = h;
   return URT_OK;
@@ -575,6 +614,7 @@ int flush_pending(urt_context* ctx) {
   URT_HIP(ctx, hipSetDevice(ctx->device));
   FrameParams P = B.P;
   P.n_frames = n;
+  P.sched_trips = sched_trip_cap(ctx, P, n);
   P.frame_group = std::max(1, std::min(P.frame_group, n));
   if (ctx->opt_xcd_run <= 0) P.xcd_run = auto_run_length(P, n);
   P.frame_stride = (unsigned int)ctx->slab_stride;
@@ -586,17 +626,41 @@ int flush_pending(urt_context* ctx) {
     if (op.kind == 0) {
       Texture* d = find_texture(ctx, op.dst);
       if (!d) return fail(ctx, URT_ERR_INVALID_HANDLE, "deferred Blit: destination texture was released");
+      // A run of AdditionShader blends of consecutive frames into one image, each possibly followed by the present of that image
+      // (RM:818-819: Blit(_target, _converged, mat); Blit(_converged, destination)) — ONE pass.  Of the presents only the last
+      // is observable: every call that could observe `destination` submits this work first, so an earlier present is overwritten
+      // unseen (as-if rule, include/urt.h); the run ends at its last present so that the image presented is the mean it was
+      // presented with.
       float samples[kMaxFramesPerLaunch];
-      size_t j = i;
-      int cnt = 0;
-      while (j < ops.size() && ops[j].kind == 0 && ops[j].dst == op.dst && ops[j].frame == op.frame + cnt && cnt < kMaxFramesPerLaunch) {
-        samples[cnt++] = ops[j].sample; j++;
+      size_t j = i, j_present = i;
+      int cnt = 0, cnt_present = 0;
+      urt_handle present = 0;
+      while (j < ops.size() && cnt <= kMaxFramesPerLaunch) {
+        const urt_context::PostOp& q = ops[j];
+        if (q.kind == 0 && q.dst == op.dst && q.frame == op.frame + cnt && cnt < kMaxFramesPerLaunch) { samples[cnt++] = q.sample; j++; }
+        else if (q.kind == 2 && q.tex == op.dst && q.dst != op.dst && q.dst != B.tex && (present == 0 || q.dst == present)) {
+          present = q.dst; j++; j_present = j; cnt_present = cnt;
+        } else break;
+      }
+      if (present) { j = j_present; cnt = cnt_present; }
+      float4* pdev = nullptr;
+      if (present) {
+        Texture* pt = find_texture(ctx, present);
+        if (!pt) return fail(ctx, URT_ERR_INVALID_HANDLE, "deferred Blit: destination texture was released");
+        pdev = pt->dev;
       }
       const float4* src = ctx->slab + (size_t)op.frame * ctx->slab_stride;
-      hipError_t e = cnt == 1 ? launch_blit_add(src, d->dev, (size_t)d->w * d->h, samples[0], ctx->stream)
-                              : launch_blit_add_multi(src, ctx->slab_stride, cnt, samples, d->dev, (size_t)d->w * d->h, ctx->stream);
+      hipError_t e = (cnt == 1 && !pdev) ? launch_blit_add(src, d->dev, (size_t)d->w * d->h, samples[0], ctx->stream)
+                                         : launch_blit_add_multi(src, ctx->slab_stride, cnt, samples, d->dev, pdev, (size_t)d->w * d->h, ctx->stream);
       if (e != hipSuccess) return fail(ctx, URT_ERR_HIP, std::string("deferred Blit: ") + hipGetErrorString(e));
       i = j;
+    } else if (op.kind == 2) {
+      Texture* t = find_texture(ctx, op.tex);
+      Texture* d = find_texture(ctx, op.dst);
+      if (!t || !d) return fail(ctx, URT_ERR_INVALID_HANDLE, "deferred Blit: texture was released");
+      const float4* img = op.tex == B.tex ? ctx->slab + (size_t)op.frame * ctx->slab_stride : t->dev;
+      URT_HIP(ctx, hipMemcpyAsync(d->dev, img, (size_t)t->w * t->h * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
+      i++;
     } else {
       Texture* t = find_texture(ctx, op.tex);
       if (!t) return fail(ctx, URT_ERR_INVALID_HANDLE, "deferred pack_rows: texture was released");
@@ -676,6 +740,7 @@ int do_dispatch(urt_context* ctx, int kernel, int gx, int gy, int gz, int first_
   // walk several triangle BVHs per Trace() (a yielding lane then continues its object-level walk sooner)
   P.blas_exit = ctx->opt_blas_exit > 0 ? ctx->opt_blas_exit : (S.n_meshes > 1 ? 9 : 14); P.shade_min = ctx->opt_shade_min; P.sky_min = ctx->opt_sky_min;
   P.n_frames = 1; P.frame_stride = 0;
+  P.sched_trips = sched_trip_cap(ctx, P, 1); P.trip_flag = ctx->d_trip_flag;
   if (P.n_strips == 0 || P.tiles_x == 0) return URT_OK;
   P.n_shards = ctx->opt_work_shards; P.frame_group = ctx->opt_frame_group;
   if (ctx->opt_xcd_run <= 0) P.xcd_run = ctx->opt_kernel_mode >= 2 ? auto_run_length(P, 1) : 1;   // (batched launches: again at submission, with the launch's frame count)
@@ -722,6 +787,10 @@ int do_dispatch(urt_context* ctx, int kernel, int gx, int gy, int gz, int first_
                   Q.first_group_row == P.first_group_row && Q.row_stride == P.row_stride && B.n < B.limit && limit > 1;
       if (!same) { int rc = flush_pending(ctx); if (rc) return rc; }
     }
+    if (limit > 1 && B.n == 0) {                          // a new batch: its Result slots (fewer, or none, when memory is short)
+      int rc = ensure_slab(ctx, res_h, *res, limit); if (rc) return rc;
+      if (!ctx->slab || ctx->slab_tex != res_h || ctx->slab_frames < 2) limit = 1;
+    }
     if (limit <= 1) {                                     // not batched: trace this frame now, straight into the texture
       FrameTable T{};
       T.f[0] = fu;
@@ -730,7 +799,6 @@ int do_dispatch(urt_context* ctx, int kernel, int gx, int gy, int gz, int first_
       if (rc) return rc;
     } else {
       if (B.n == 0) {
-        int rc = ensure_slab(ctx, res_h, *res, limit); if (rc) return rc;
         B.limit = std::min(limit, ctx->slab_frames);
         B.tex = res_h; B.scene_epoch = ctx->scene_epoch; B.S = S; B.P = P; B.front_mode = front_mode; B.count = count;
       }
@@ -793,7 +861,7 @@ int do_dispatch(urt_context* ctx, int kernel, int gx, int gy, int gz, int first_
 
 extern "C" {
 
-int urt_abi_version(void) { return 2; }
+int urt_abi_version(void) { return 3; }
 
 int urt_device_count(int* out_count) {
   if (!out_count) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "out_count is NULL");
@@ -823,8 +891,16 @@ int urt_context_create(int device, urt_context** out_ctx) {
   if (e == hipSuccess) e = hipMemset(ctx->d_counters, 0, sizeof(DevCounters) * kCounterShards);
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_next, kWorkShards * 128 + 65536 * 16 * sizeof(unsigned long long));   // work-counter shards; the rest: diagnostic stamps (URT_STAMPS builds)
   if (e == hipSuccess) e = hipMemset(ctx->d_next, 0, kWorkShards * 128 + 65536 * 16 * sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->h_trip_flag, 64, hipHostMallocMapped | hipHostMallocCoherent);   // the watchdog word the kernels raise (system-scope atomic)
+  if (e == hipSuccess) { *ctx->h_trip_flag = 0; e = hipHostGetDevicePointer((void**)&ctx->d_trip_flag, ctx->h_trip_flag, 0); }
   if (e == hipSuccess) { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n > 0) ctx->n_cus = n; }
-  if (e != hipSuccess) { (void)hipStreamDestroy(ctx->own_stream); delete ctx; return fail(nullptr, URT_ERR_HIP, std::string("counter allocation: ") + hipGetErrorString(e)); }
+  if (e != hipSuccess) {
+    if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+    if (ctx->d_next) (void)hipFree(ctx->d_next);
+    if (ctx->h_trip_flag) (void)hipHostFree(ctx->h_trip_flag);
+    (void)hipStreamDestroy(ctx->own_stream); delete ctx;
+    return fail(nullptr, URT_ERR_HIP, std::string("counter allocation: ") + hipGetErrorString(e));
+  }
   *out_ctx = ctx;
   return URT_OK;
   URT_GUARD_END(nullptr)
@@ -849,6 +925,7 @@ int urt_context_destroy(urt_context* ctx) {
   if (ctx->d_mail) (void)hipFree(ctx->d_mail);
   if (ctx->d_tables) (void)hipFree(ctx->d_tables);
   if (ctx->h_tables) (void)hipHostFree(ctx->h_tables);
+  if (ctx->h_trip_flag) (void)hipHostFree(ctx->h_trip_flag);
   for (hipEvent_t e : ctx->table_ev) if (e) (void)hipEventDestroy(e);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
@@ -884,7 +961,7 @@ int urt_synchronize(urt_context* ctx) {
   URT_HIP(ctx, hipSetDevice(ctx->device));
   { int rc = flush_pending(ctx); if (rc) return rc; }
   URT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return URT_OK;
+  return check_watchdog(ctx);
 }
 
 /* ---- ComputeBuffer ---- */
@@ -988,7 +1065,7 @@ int urt_texture_get_pixels(urt_context* ctx, urt_handle texture, float* rgba) {
   { int rc = flush_pending(ctx); if (rc) return rc; }
   URT_HIP(ctx, hipMemcpyAsync(rgba, t->dev, (size_t)t->w * t->h * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
   URT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return URT_OK;
+  return check_watchdog(ctx);                           // pixels of a launch that hit a cap are not handed out as good
 }
 
 int urt_texture_get_info(urt_context* ctx, urt_handle texture, int* out_width, int* out_height, void** out_device_ptr) {
@@ -1111,8 +1188,8 @@ int urt_blit_add(urt_context* ctx, urt_handle src, urt_handle dst, float sample)
   urt_context::Pending& B = ctx->pend;
   if (B.n > 0 && src == B.tex && dst != src && (const float4*)d->dev != B.S.sky) {
     // the source is a frame that has not been traced yet: the blend is deferred with it (flush_pending runs it in order)
+    // (a full batch is submitted by the next dispatch or observer — the present of this frame, RM:819, may still follow)
     B.ops.push_back(urt_context::PostOp{0, B.n - 1, src, dst, sample, 0, 1, nullptr});
-    if (B.n >= B.limit) return flush_pending(ctx);        // the batch is full and its last frame's blend is in: go
     return URT_OK;
   }
   { int rc = flush_pending(ctx); if (rc) return rc; }
@@ -1128,10 +1205,22 @@ int urt_blit(urt_context* ctx, urt_handle src, urt_handle dst) {
   if (!s || !d) return fail(ctx, URT_ERR_INVALID_HANDLE, "Blit: unknown texture handle");
   if (s->w != d->w || s->h != d->h) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "Blit: source and destination sizes differ");
   URT_HIP(ctx, hipSetDevice(ctx->device));
+  URT_GUARD_BEGIN
+  urt_context::Pending& B = ctx->pend;
+  if (B.n > 0 && dst != B.tex && dst != src && (const float4*)d->dev != B.S.sky) {
+    // frames are deferred: the copy is queued behind them, in program order (the present of RM:819 — its source is the image
+    // the deferred blends accumulate into).  flush_pending fuses it into the blend pass.
+    d->other_writes = true;
+    B.ops.push_back(urt_context::PostOp{2, B.n - 1, src, dst, 0.0f, 0, 1, nullptr});
+    if (B.n >= B.limit) return flush_pending(ctx);        // the batch is full and its last frame is presented: go
+    return URT_OK;
+  }
   { int rc = flush_pending(ctx); if (rc) return rc; }
   d->other_writes = true;
-  URT_HIP(ctx, hipMemcpyAsync(d->dev, s->dev, (size_t)s->w * s->h * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
+  if (dst != src)
+    URT_HIP(ctx, hipMemcpyAsync(d->dev, s->dev, (size_t)s->w * s->h * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
   return URT_OK;
+  URT_GUARD_END(ctx)
 }
 
 static int pack_impl(urt_context* ctx, urt_handle texture, int first_group_row, int row_stride, void* dense, bool to_dense,
@@ -1170,7 +1259,11 @@ int urt_texture_unpack_rows_on(urt_context* ctx, urt_handle texture, int first_g
   Texture* t = find_texture(ctx, texture);
   if (!t) return fail(ctx, URT_ERR_INVALID_HANDLE, "unknown texture handle");
   if (first_group_row < 0 || row_stride < 1) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "bad strip arguments");
-  if (ctx->pend.n > 0 && ctx->pend.tex == texture) { int rc = flush_pending(ctx); if (rc) return rc; }   // never the case for a gather target
+  if (ctx->pend.n > 0) {                                  // never the case for a dedicated gather target
+    bool touched = ctx->pend.tex == texture;
+    for (const urt_context::PostOp& q : ctx->pend.ops) touched = touched || q.tex == texture || q.dst == texture;
+    if (touched) { int rc = flush_pending(ctx); if (rc) return rc; }
+  }
   if (in_slab(ctx, *t)) { int rc = detach_from_slab(ctx, *t); if (rc) return rc; }
   int group_rows = (t->h + 7) / 8;
   int n_strips = first_group_row < group_rows ? (group_rows - first_group_row + row_stride - 1) / row_stride : 0;
@@ -1278,6 +1371,9 @@ int urt_set_option(urt_context* ctx, const char* name, int value) {
   } else if (std::strcmp(name, "work_shards") == 0) {
     if (value < 1 || value > (int)kWorkShards || (value & (value - 1))) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "work_shards must be a power of two in [1, 64]");
     ctx->opt_work_shards = value;
+  } else if (std::strcmp(name, "watchdog_cap") == 0) {
+    if (value < 0) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "watchdog_cap must be >= 0 (0 = auto)");
+    ctx->opt_watchdog_cap = value;
   } else if (std::strcmp(name, "xcd_run") == 0) {
     if (value < 0 || value > 4096) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "xcd_run must be in [0, 4096] (0 = auto)");
     ctx->opt_xcd_run = value;
@@ -1315,6 +1411,7 @@ int urt_reset_counters(urt_context* ctx) {
   URT_HIP(ctx, hipStreamSynchronize(ctx->stream));
   resolve_timing(ctx);
   URT_HIP(ctx, hipMemset(ctx->d_counters, 0, sizeof(DevCounters) * kCounterShards));
+  if (ctx->h_trip_flag) __atomic_store_n(ctx->h_trip_flag, 0u, __ATOMIC_RELEASE);
   ctx->dispatches = 0;
   ctx->launches = 0;
   ctx->pixels_dispatched = 0;

@@ -33,8 +33,12 @@ struct urt_group {
   std::vector<void*> recv;                             // [rank] on rank 0's device:   kSlots x stage_bytes
   std::vector<std::vector<hipEvent_t>> ev_copy;        // [rank][slot] the peer copy of that slot has landed on rank 0
   std::vector<std::vector<hipEvent_t>> ev_free;        // [rank][slot] rank 0 has unpacked it (the slot may be reused)
-  struct PendingGather { urt_handle src, dst; };
-  std::vector<PendingGather> pending;                  // gathers whose packs are queued but whose copies are not issued yet
+  // gathers whose packs are queued but whose copies are not issued yet (kind 0, staging slot `slot`), and — in program order
+  // between them — the plain blits that read or write an image such a gather writes (kind 1: the present of the gathered image,
+  // RM:819): they must run after the unpack that is still to be issued
+  struct PendingGather { int kind; urt_handle src, dst; int slot; };
+  std::vector<PendingGather> pending;
+  int pending_gathers = 0;
   uint64_t gathers = 0;
 };
 
@@ -78,9 +82,12 @@ void free_staging(urt_group* g) {
   g->stage.clear(); g->recv.clear(); g->stage_bytes = 0;
 }
 
+int flush_gathers(urt_group* g);
+
 int ensure_staging(urt_group* g, size_t bytes) {
   if (bytes <= g->stage_bytes) return URT_OK;
-  for (urt_context* c : g->ctx) { int rc = urt_synchronize(c); if (rc) return gfail(g, rc, urt_last_error(c)); }   // queued gathers use the old buffers
+  { int rc = flush_gathers(g); if (rc) return rc; }                      // queued gathers have packed into the old buffers: copy + unpack them first
+  for (urt_context* c : g->ctx) { int rc = urt_synchronize(c); if (rc) return gfail(g, rc, urt_last_error(c)); }
   free_staging(g);
   size_t n = g->ctx.size();
   g->stage.assign(n, nullptr); g->recv.assign(n, nullptr);
@@ -103,6 +110,7 @@ int flush_gathers(urt_group* g) {
   int dev0 = urtd::context_device(root);
   std::vector<urt_group::PendingGather> todo;
   todo.swap(g->pending);
+  g->pending_gathers = 0;
   for (size_t r = 0; r < n; r++) {
     urt_context* c = g->ctx[r];
     int rc = urt_flush(c);                                              // the packs were queued behind the frames they read
@@ -110,24 +118,41 @@ int flush_gathers(urt_group* g) {
     int dev = urtd::context_device(c);
     hipStream_t st = urtd::context_stream(c);
     GROUP_HIP(g, hipSetDevice(dev));
-    for (size_t s = 0; s < todo.size(); s++) {
-      char* src = (char*)g->stage[r] + s * g->stage_bytes;
-      char* dst = (char*)g->recv[r] + s * g->stage_bytes;
-      GROUP_HIP(g, hipMemcpyPeerAsync(dst, dev0, src, dev, g->stage_bytes, st));   // xGMI point-to-point (or on-device when the ordinals coincide)
-      GROUP_HIP(g, hipEventRecord(g->ev_copy[r][s], st));
+    for (const urt_group::PendingGather& op : todo) {
+      if (op.kind == 0) {
+        char* src = (char*)g->stage[r] + (size_t)op.slot * g->stage_bytes;
+        char* dst = (char*)g->recv[r] + (size_t)op.slot * g->stage_bytes;
+        GROUP_HIP(g, hipMemcpyPeerAsync(dst, dev0, src, dev, g->stage_bytes, st));   // xGMI point-to-point (or on-device when the ordinals coincide)
+        GROUP_HIP(g, hipEventRecord(g->ev_copy[r][(size_t)op.slot], st));
+      } else if (r != 0) {
+        rc = urt_blit(c, op.src, op.dst);                               // replicated like every blit (only rank 0's copy shows the gathered image)
+        if (rc) return rank_fail(g, (int)r, rc);
+      }
     }
   }
   GROUP_HIP(g, hipSetDevice(dev0));
   hipStream_t st0 = urtd::context_stream(root);
-  for (size_t s = 0; s < todo.size(); s++) {
-    for (size_t r = 0; r < n; r++) {
-      GROUP_HIP(g, hipStreamWaitEvent(st0, g->ev_copy[r][s], 0));
-      int rc = urt_texture_unpack_rows(root, todo[s].dst, (int)r, (int)n, (char*)g->recv[r] + s * g->stage_bytes);
+  for (const urt_group::PendingGather& op : todo) {
+    if (op.kind == 1) {                                                 // in program order after the unpacks before it
+      int rc = urt_blit(root, op.src, op.dst);
       if (rc) return rank_fail(g, 0, rc);
-      GROUP_HIP(g, hipEventRecord(g->ev_free[r][s], st0));
+      continue;
+    }
+    for (size_t r = 0; r < n; r++) {
+      GROUP_HIP(g, hipStreamWaitEvent(st0, g->ev_copy[r][(size_t)op.slot], 0));
+      int rc = urt_texture_unpack_rows(root, op.dst, (int)r, (int)n, (char*)g->recv[r] + (size_t)op.slot * g->stage_bytes);
+      if (rc) return rank_fail(g, 0, rc);
+      GROUP_HIP(g, hipEventRecord(g->ev_free[r][(size_t)op.slot], st0));
     }
   }
   return URT_OK;
+}
+
+// does a queued gather (or a blit queued with them) read or write one of these images?
+bool touches_pending(const urt_group* g, urt_handle a, urt_handle b) {
+  for (const urt_group::PendingGather& op : g->pending)
+    if (op.src == a || op.dst == a || (b && (op.src == b || op.dst == b))) return true;
+  return false;
 }
 
 }  // namespace
@@ -220,7 +245,10 @@ int urt_group_texture_create(urt_group* g, int width, int height, urt_handle* ou
   int args[2] = {width, height};
   return create_replicated(g, out_texture, "texture_create", [](urt_context* c, void* a, urt_handle* h) { return urt_texture_create(c, ((int*)a)[0], ((int*)a)[1], h); }, args);
 }
-int urt_group_texture_set_pixels(urt_group* g, urt_handle texture, const float* rgba) { FORWARD(g, urt_texture_set_pixels(c, texture, rgba)); }
+int urt_group_texture_set_pixels(urt_group* g, urt_handle texture, const float* rgba) {
+  if (g && touches_pending(g, texture, 0)) { int rc = flush_gathers(g); if (rc) return rc; }   // a queued unpack must not land on top of these pixels
+  FORWARD(g, urt_texture_set_pixels(c, texture, rgba));
+}
 int urt_group_texture_release(urt_group* g, urt_handle texture) {
   if (g) { int rc = flush_gathers(g); if (rc) return rc; }
   FORWARD(g, urt_texture_release(c, texture));
@@ -235,8 +263,19 @@ int urt_group_set_option(urt_group* g, const char* name, int value) {
   if (g) { int rc = flush_gathers(g); if (rc) return rc; }
   FORWARD(g, urt_set_option(c, name, value));
 }
-int urt_group_blit_add(urt_group* g, urt_handle src, urt_handle dst, float sample) { FORWARD(g, urt_blit_add(c, src, dst, sample)); }
-int urt_group_blit(urt_group* g, urt_handle src, urt_handle dst) { FORWARD(g, urt_blit(c, src, dst)); }
+int urt_group_blit_add(urt_group* g, urt_handle src, urt_handle dst, float sample) {
+  if (g && touches_pending(g, src, dst)) { int rc = flush_gathers(g); if (rc) return rc; }     // in order with the unpack that is still to be issued
+  FORWARD(g, urt_blit_add(c, src, dst, sample));
+}
+int urt_group_blit(urt_group* g, urt_handle src, urt_handle dst) {
+  if (g && touches_pending(g, src, dst)) {
+    // the present of a gathered image (gather(_converged -> full); Blit(full, destination), RM:819): queued with the gathers, it
+    // runs right after the unpack it depends on — the ranks keep batching their frames
+    g->pending.push_back(urt_group::PendingGather{1, src, dst, 0});
+    return URT_OK;
+  }
+  FORWARD(g, urt_blit(c, src, dst));
+}
 
 /* ---- the partitioned dispatch and the frame-end gather ---- */
 int urt_group_shader_dispatch(urt_group* g, int kernel, int groups_x, int groups_y, int groups_z) {
@@ -262,7 +301,7 @@ int urt_group_gather(urt_group* g, urt_handle src_texture, urt_handle dst_textur
   rc = urt_texture_pack_rows(g->ctx[0], src_texture, 0, (int)n, nullptr, &bytes);     // rank 0 has the most strips
   if (rc) return rank_fail(g, 0, rc);
   if ((rc = ensure_staging(g, (size_t)bytes))) return rc;
-  size_t slot = g->pending.size();
+  size_t slot = (size_t)g->pending_gathers;
   for (size_t r = 0; r < n; r++) {
     urt_context* c = g->ctx[r];
     // the slot's previous use must have been unpacked on rank 0 before this rank's next peer copy overwrites the receive
@@ -272,12 +311,13 @@ int urt_group_gather(urt_group* g, urt_handle src_texture, urt_handle dst_textur
     rc = urt_texture_pack_rows(c, src_texture, (int)r, (int)n, (char*)g->stage[r] + slot * g->stage_bytes, nullptr);   // deferred behind the rank's batched frames
     if (rc) return rank_fail(g, (int)r, rc);
   }
-  g->pending.push_back(urt_group::PendingGather{src_texture, dst_texture});
+  g->pending.push_back(urt_group::PendingGather{0, src_texture, dst_texture, (int)slot});
+  g->pending_gathers++;
   g->gathers++;
   // submit when the burst is full, or at once when the ranks are not deferring frames (then there is nothing to wait for)
   bool deferring = false;
   for (urt_context* c : g->ctx) deferring = deferring || urtd::context_pending_frames(c) > 0;
-  if (!deferring || g->pending.size() >= (size_t)urt_group::kSlots) return flush_gathers(g);
+  if (!deferring || g->pending_gathers >= urt_group::kSlots) return flush_gathers(g);
   return URT_OK;
 }
 

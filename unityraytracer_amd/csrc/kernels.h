@@ -24,9 +24,10 @@ hipError_t launch_sched(const DevScene& S, const FrameParams& P, const FrameUnif
 hipError_t launch_serve(const DevScene& S, const FrameParams& P, const FrameUniforms* T, float4* result, DevCounters* ctr,
                         unsigned int* next, float4* mail, int n_blocks, int front_mode, bool count, hipStream_t st);
 // fused AdditionShader blends of n consecutive frames into one image: dst = blend(... blend(blend(dst, src_0), src_1) ..., src_{n-1})
-// in that order per pixel — the same operations as n launch_blit_add calls; src_f = src + f * frame_stride
-hipError_t launch_blit_add_multi(const float4* src, size_t frame_stride, int n, const float* samples, float4* dst, size_t n_pixels,
-                                 hipStream_t st);
+// in that order per pixel — the same operations as n launch_blit_add calls; src_f = src + f * frame_stride.  `present` (or null)
+// also receives the final value: the copy Graphics.Blit(dst, present) would make after the last blend (RM:819)
+hipError_t launch_blit_add_multi(const float4* src, size_t frame_stride, int n, const float* samples, float4* dst, float4* present,
+                                 size_t n_pixels, hipStream_t st);
 size_t sched_lds_bytes(const DevScene& S, const FrameParams& P);          // dynamic LDS of one workgroup (4 waves) of mode 3
 // mode 4: persistent waves over a pool of 64*k paths per wave kept in LDS, phases run on compacted lanes
 hipError_t launch_pool(const DevScene& S, const FrameParams& P, float4* result, DevCounters* ctr, unsigned int* next,

@@ -984,7 +984,13 @@ __device__ __forceinline__ int front_listed(const DevScene& S, const FrameParams
 // functions) — only WHEN and WHERE a lane executes them changes, so pixels are bit-identical.
 // ---------------------------------------------------------------------------------------------------
 enum : int { ST_DEAD = 0, ST_FRONT = 1, ST_RESUME = 2, ST_BLAS = 3, ST_SHADE = 4, ST_SKY = 5 };
-static constexpr unsigned int kWatchdogIters = 1u << 24;    // scheduler trips per wave (a frame needs ~1e3-1e5)
+// Every persistent kernel leaves its scheduler loop after P.sched_trips trips per wave, whatever the data (a frame needs ~1e3-1e5;
+// the host scales the cap with the launch: frames x rays x bounces, context.cpp).  A wave that leaves that way — or through the
+// per-phase traversal cap — counts itself in DevCounters::watchdog and raises the host-visible flag: its pixels are missing.
+__device__ __forceinline__ void report_watchdog(const FrameParams& P, DevCounters* shard) {
+  atomicAdd(&shard->watchdog, 1ull);
+  if (P.trip_flag) __hip_atomic_fetch_add(P.trip_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 #ifndef URT_SCHED_OCC
 #define URT_SCHED_OCC 5
@@ -1089,7 +1095,7 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
       nD = __popcll(wballot(st == ST_DEAD));
     }
     bool can_refill = !exhausted && nD >= P.refill_min;
-    if (++wave_iters > kWatchdogIters) { watchdog = true; break; }   // an exit every wave reaches, whatever the data
+    if (++wave_iters > P.sched_trips) { watchdog = true; break; }   // an exit every wave reaches, whatever the data
     int phase;
     int exit_below = 1;              // traversal runs to completion unless other lanes can make progress meanwhile
     // Surface shading is the longest straight-line code (~750 VALU whatever the lane count, the sky lookup ~270): a thin batch
@@ -1233,7 +1239,7 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
     sp_[w + 12] = t_begin; sp_[w + 13] = wall_clock64(); sp_[w + 14] = t_dry; sp_[w + 15] = __builtin_amdgcn_s_memtime() - c_begin;
   }
 #endif
-  if (watchdog && (threadIdx.x & 63) == 0) atomicAdd(&ctr->watchdog, 1ull);
+  if (watchdog && (threadIdx.x & 63) == 0) report_watchdog(P, ctr);
   lc.rays = (threadIdx.x & 63) == 0 ? wave_rays : 0u;
   flush_counters<COUNT>(lc, ctr);
 }
@@ -1392,7 +1398,7 @@ __global__ __launch_bounds__(BLOCK, URT_SERVE_OCC) void k_serve(DevScene S, Fram
       nD = __popcll(wballot(st == ST_DEAD));
     }
     bool can_refill = !exhausted && nD >= P.refill_min;
-    if (++wave_iters > kWatchdogIters) { watchdog = true; break; }   // an exit every wave reaches, whatever the data
+    if (++wave_iters > P.sched_trips) { watchdog = true; break; }   // an exit every wave reaches, whatever the data
     int phase;
     bool sky_too = false;
     if (av >= P.blas_min) phase = ST_BLAS;
@@ -1592,7 +1598,7 @@ __global__ __launch_bounds__(BLOCK, URT_SERVE_OCC) void k_serve(DevScene S, Fram
       }
     }
   }
-  if (watchdog && (threadIdx.x & 63) == 0) atomicAdd(&ctr->watchdog, 1ull);
+  if (watchdog && (threadIdx.x & 63) == 0) report_watchdog(P, ctr);
   if (COUNT && (threadIdx.x & 63) == 0) {
     DevCounters* c = ctr + (blockIdx.x & (kCounterShards - 1));
     for (int q = 0; q < 6; q++) if (sv[q]) atomicAdd(&c->serve[q], sv[q]);
@@ -1686,7 +1692,7 @@ __global__ __launch_bounds__(64) void k_pool(DevScene S, FrameParams P, float4* 
       nPin += __popcll(wballot(v == PS_PINNED));
       nShade += __popcll(wballot(v == PS_SHADE));
     }
-    if (++wave_iters > kWatchdogIters) { watchdog = true; break; }   // an exit every wave reaches, whatever the data
+    if (++wave_iters > P.sched_trips) { watchdog = true; break; }   // an exit every wave reaches, whatever the data
     const int busy = nFront + nNew + nPin + nShade;
     // ---- phase election ----
     // The triangle-BVH phase is the expensive one (hundreds of dependent steps per quantum, each costing the same whether
@@ -1874,7 +1880,7 @@ __global__ __launch_bounds__(64) void k_pool(DevScene S, FrameParams P, float4* 
 #undef PF
 #undef PFf
 #undef PFset
-  if (watchdog && (threadIdx.x & 63) == 0) atomicAdd(&ctr[blockIdx.x & (kCounterShards - 1)].watchdog, 1ull);
+  if (watchdog && (threadIdx.x & 63) == 0) report_watchdog(P, ctr + (blockIdx.x & (kCounterShards - 1)));
   flush_counters<COUNT>(lc, ctr);
 }
 
@@ -1979,9 +1985,12 @@ __global__ __launch_bounds__(256) void k_blit_add(const float4* __restrict__ src
 
 // n consecutive blends in one pass (frames of a batched launch): per pixel the SAME operations in the same order as n
 // k_blit_add launches, with 16 (n + 2) bytes of traffic per pixel instead of 48 n.
+// `present` (may be null): the image the host presents the accumulated frame to after every blend (Graphics.Blit(_converged,
+// destination), RM:819).  Of the n presents of a fused run only the last is observable (every observer of `present` submits the
+// deferred work first, context.cpp), so the last blended value is stored to both images: the bytes a copy of dst would carry.
 struct BlendSamples { float s[kMaxFramesPerLaunch]; };
 __global__ __launch_bounds__(256) void k_blit_add_multi(const float4* __restrict__ src, size_t frame_stride, int n, BlendSamples smp,
-                                                        float4* __restrict__ dst, size_t npix) {
+                                                        float4* __restrict__ dst, float4* __restrict__ present, size_t npix) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (size_t)gridDim.x * blockDim.x) {
     float4 c = dst[i];
     for (int f = 0; f < n; f++) {
@@ -1994,6 +2003,7 @@ __global__ __launch_bounds__(256) void k_blit_add_multi(const float4* __restrict
       c.w = a * a + c.w * ia;
     }
     dst[i] = c;
+    if (present) present[i] = c;
   }
 }
 
@@ -2222,15 +2232,15 @@ hipError_t launch_blit_add(const float4* src, float4* dst, size_t n_pixels, floa
   return hipGetLastError();
 }
 
-hipError_t launch_blit_add_multi(const float4* src, size_t frame_stride, int n, const float* samples, float4* dst, size_t n_pixels,
-                                 hipStream_t st) {
+hipError_t launch_blit_add_multi(const float4* src, size_t frame_stride, int n, const float* samples, float4* dst, float4* present,
+                                 size_t n_pixels, hipStream_t st) {
   if (n_pixels == 0 || n <= 0) return hipSuccess;
   if (n > kMaxFramesPerLaunch) return hipErrorInvalidValue;
   BlendSamples smp{};
   for (int f = 0; f < n; f++) smp.s[f] = samples[f];
   size_t nb = (n_pixels + 255) / 256;
   if (nb > 4096) nb = 4096;
-  hipLaunchKernelGGL(k_blit_add_multi, dim3((unsigned)nb), dim3(256), 0, st, src, frame_stride, n, smp, dst, n_pixels);
+  hipLaunchKernelGGL(k_blit_add_multi, dim3((unsigned)nb), dim3(256), 0, st, src, frame_stride, n, smp, dst, present, n_pixels);
   return hipGetLastError();
 }
 

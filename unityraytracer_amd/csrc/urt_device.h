@@ -73,6 +73,8 @@ struct FrameParams {
   int pool_inloop;          // modes 4, 5: idle lanes that trigger a re-feed of the traversal phase from the waiting rays (1..64)
   int pool_other_min;       // mode 4: lanes of FRONT / SHADE work that make those phases worth a trip while rays queue for the BVH
   unsigned int watchdog_steps;  // cap on traversal trips per scheduled BLAS phase: a few times (nodes + leaves) of the scene
+  unsigned int sched_trips;     // persistent modes: cap on scheduler trips per wave, scaled with the launch (frames x rays x bounces; context.cpp)
+  unsigned int* trip_flag;      // host-mapped word: a wave that leaves through a cap adds 1 (the next synchronising call reports URT_ERR_WATCHDOG)
   // mode 3, frame batching: ONE launch traces n_frames consecutive frames of the same scene/resolution (the library defers
   // dispatches, context.cpp).  Frame f's uniforms are entry f of the launch's table in device memory; its Result image starts
   // at result + f * frame_stride.  The c2w/invp/pixel_off/seed above are those of frame 0 (all the other kernel modes read).
