@@ -262,7 +262,10 @@ def main():
     total_rays = float(rays.item())
 
     # ---- roofline of the dominant kernel (rank 0): replay the same frames with traversal counters on -----------
+    # `issue` (beside it): what bounds the kernel once SURVEY 8(d)'s byte fraction saturates (C2 / C3D exceed 1: the bytes come from
+    # LDS / L2) — VALU issue rate, lane utilisation and the share of wave cycles spent waiting, from the committed SQ_* passes
     roofline = None
+    issue = None
     cpu = None
     if rank == 0:
         # trace_ms = sum of the trace launches' own HIP-event durations (recorded by the library on the stream it launches
@@ -285,14 +288,16 @@ def main():
         achieved = alg / (launch_ms * 1e-3) / 1e9
         # HBM-side traffic is NOT measured in this run (PMC needs rocprofv3): it is the committed figure of the last profiled
         # build, per launch of the same shape, or null when that profile is of another configuration / batch size
-        traffic, traffic_source = None, None
+        traffic, traffic_source, issue = None, None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")       # written from rocprofv3 --pmc passes (profiles/README.md)
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and world == 1 and args.kernel_mode in (None, 3):
             try:
-                j = json.load(open(pmc)).get("configs", {}).get(args.config)
-                if j and world == 1 and abs((j.get("frames_per_launch") or 1) - frames_per_launch) < 0.51:
+                j = json.load(open(pmc)).get("configs", {}).get(args.config) or {}
+                j = (j.get("by_frames_per_launch") or {}).get(str(int(round(frames_per_launch))))     # the entry of THIS launch shape
+                if j:
                     traffic = j.get("hbm_bytes_per_launch")
-                    traffic_source = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command, not this run)"
+                    traffic_source = f"profiles/pmc_traffic.json ({j.get('round')}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `{j.get('command')}`, an earlier run of this launch shape — not measured in this run)"
+                    issue = j.get("issue")
             except Exception:
                 traffic = None
         # k_sched<COUNT, BLOCK, FMODE, MULTI>: FMODE 0 one mesh, 2 listed FRONT (2..12 MeshObjects), 1 more than that (kernels.hip)
@@ -365,7 +370,7 @@ def main():
                        "partition": (f"8-row strips round-robin over ranks, one gather per frame; {burst} frames per launch, each burst's gathers" + (" overlap the next burst's rendering" if overlap else " serialised")) if world > 1 else "single GPU",
                        "rays_per_step": int(total_rays / args.steps), "kernel_mode": args.kernel_mode if args.kernel_mode is not None else 3,
                        **({"gather_every": args.gather_every} if world > 1 else {})},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "issue": issue, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
     master.OnDisable()

@@ -186,8 +186,8 @@ typedef struct urt_counters {
  *          mode 3: "blas_min" / "blas_exit" (0 = auto by scene | 1..64) / "shade_min" / "sky_min" (1..64): vote thresholds, "shade_split" (-1 auto | 0 | 1: surface hits and
  *                  sky misses as separate phases), "sched_block" (0 auto | 64 | 256),
  *                  "top_nodes" (0..256 triangle-BVH nodes kept in LDS), "top_front" (-1 auto | 0 | 1: where that top is
- *                  walked), "front_list" (-1 auto | 0 | 1: scenes of <= 12 MeshObjects collect the objects a ray must test in a list
- *                  and work the lists off in voted trips), "lds_tlas" (0/1: small object-level tables in LDS),
+ *                  walked), "front_list" (-1 auto | 0 | 1 | 2: multi-mesh scenes determine the objects a ray must test first and work them off in voted
+ *                  trips — auto / 1: by mask arithmetic over the heap when it has <= 31 nodes, else as a list when <= 12 MeshObjects; 2: always the list), "lds_tlas" (0/1: small object-level tables in LDS),
  *          mode 4: "pool_k" (1..4), "pool_refill", "pool_blas_min" (1..256), "pool_blas_exit", "pool_inloop",
  *                  "pool_other_min" (1..64),
  *          "blas_leaf_max" (1..8: triangles per BVH leaf; rebuilds the BVH),

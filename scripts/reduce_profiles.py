@@ -1,11 +1,15 @@
 """Reduce gpurun_out/prof_<CONFIG> (scripts/collect_profiles.sh) to the small files kept under profiles/:
    <prefix>_kernel_stats.csv, <prefix>_pmc_k_sched.json, <prefix>_bench.json.log, and the config's entry of pmc_traffic.json.
-   usage: python scripts/reduce_profiles.py CONFIG [round-prefix, default r02]"""
+   usage: python scripts/reduce_profiles.py CONFIG [round-prefix, default r03] [TAG]      (TAG as given to collect_profiles.sh)
+   pmc_traffic.json is keyed by config AND frames per launch (configs[cfg]["by_frames_per_launch"]["20"]): bench.py looks the
+   entry of its own launch shape up for `roofline.traffic` and the `issue` object."""
 import csv, glob, json, os, shutil, sys
 cfg = sys.argv[1] if len(sys.argv) > 1 else "C3"
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
-src = f"gpurun_out/prof_{cfg}"
-prefix = f"{rnd}_bench_{cfg.lower()}"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r03"
+tag = sys.argv[3] if len(sys.argv) > 3 else ""
+src = f"gpurun_out/prof_{cfg}{tag}"
+prefix = f"{rnd}_bench_{cfg.lower()}{tag}"
+command = open(os.path.join(src, "command.txt")).read().strip() if os.path.exists(os.path.join(src, "command.txt")) else f"python3 bench.py --config {cfg}"
 dst = "profiles"
 KERNEL = "k_sched<false"   # the timed trace kernel (the counting replay is k_sched<true ...)
 
@@ -58,13 +62,29 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
     except Exception: allcfg = {}
     if "configs" not in allcfg: allcfg = {"configs": {}}
     rl = bench.get("roofline") or {}
-    allcfg["configs"][cfg] = {
-        "kernel": kname, "round": rnd, "frames_per_launch": rl.get("frames_per_launch"),
+    fpl = rl.get("frames_per_launch")
+    entry = {
+        "kernel": kname, "round": rnd, "frames_per_launch": fpl, "command": command,
         "FETCH_SIZE_KB_per_launch": pmc["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": pmc["WRITE_SIZE"],
         "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request -> doubled (MI355X_MICROARCH.md 'HBM'); WRITE_SIZE exact",
         "hbm_bytes_per_launch": hbm, "rocprof_timed_launch_ms": None if not stats or last_ns is None else last_ns / 1e6,
         "rocprof_avg_launch_ms": None if avg_ns is None else avg_ns / 1e6, "rocprof_launches": calls,
         "bench_launch_ms": rl.get("launch_ms"), "algorithmic_bytes_per_launch": rl.get("algorithmic_bytes_per_launch"), "frac": rl.get("frac"),
-        "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --config {cfg} --no-cpu-baseline (defaults: 8 warm-up + 256 timed frames); the LAST launch of the timed kernel in the run = 64 timed frames"}
+        "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- {command} --no-cpu-baseline; the LAST launch of the timed kernel in the run"}
+    # what bounds the kernel when the byte fraction saturates: issue-side figures of the same launch (separate SQ_* passes)
+    need = ("SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE")
+    if all(k in pmc for k in need):
+        cycles = pmc["GRBM_GUI_ACTIVE"] / 8.0                     # per XCD: the launch's active cycles
+        entry["issue"] = {
+            "valu_frac": round(pmc["SQ_INSTS_VALU"] / 1024.0 / cycles / 0.5, 4),      # of one wave64 VALU instruction per 2 cycles per SIMD (1024 SIMDs)
+            "lane_util": round(pmc["SQ_THREAD_CYCLES_VALU"] / (pmc["SQ_INSTS_VALU"] * 64.0), 4),
+            "wait_frac": round(pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"], 4),
+            "valu_insts_per_frame": None if not fpl else round(pmc["SQ_INSTS_VALU"] / fpl),
+            "source": f"profiles/{prefix}_pmc_k_sched.json: SQ_INSTS_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE/8 cycles x 0.5), SQ_THREAD_CYCLES_VALU / (SQ_INSTS_VALU x 64), SQ_WAIT_ANY / SQ_WAVE_CYCLES of the last timed launch"}
+    c = allcfg["configs"].setdefault(cfg, {})
+    if "by_frames_per_launch" not in c:                           # (round-2 layout: one flat entry per config)
+        old = dict(c); c.clear(); c["by_frames_per_launch"] = {}
+        if old: c["by_frames_per_launch"][str(int(round(old.get("frames_per_launch") or 1)))] = old
+    c["by_frames_per_launch"][str(int(round(fpl or 1)))] = entry
     json.dump(allcfg, open(path, "w"), indent=1)
-    print("hbm bytes per launch", hbm)
+    print("hbm bytes per launch", hbm, entry.get("issue"))

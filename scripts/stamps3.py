@@ -40,6 +40,12 @@ for (w, h, b), wpc in itertools.product(((1920, 1080, 8),), (20,)):
     for q in range(3):
         print(f"   {names[q]:5s}: {t[:, q].sum() / life.sum() * 100:5.1f} % of wave time, {trips[:, q].mean():7.1f} trips/wave, {lanes[:, q].sum() / max(1, trips[:, q].sum()):5.1f} lanes/trip, {t[:, q].sum() / max(1, trips[:, q].sum()):7.2f} us/trip")
     print(f"   BLAS inner: {trips[:, 3].mean():8.1f} steps/wave, {lanes[:, 3].sum() / max(1, trips[:, 3].sum()):5.1f} active lanes/step, {t[:, 1].sum() / max(1, trips[:, 3].sum()) * 1000:7.1f} ns/step")
+    fs = st[:, 25:32].astype(np.float64)
+    if fs[:, 3].sum() > 0:                                       # listed FRONT: where its time goes
+        ft = t[:, 0].sum()
+        print(f"   FRONT split: heap walk {fs[:, 0].sum() / 100 / ft * 100:5.1f} % ({fs[:, 0].sum() / 100 / fs[:, 3].sum():6.2f} us per walk, {fs[:, 6].sum() / fs[:, 3].sum():5.1f} fresh lanes), "
+              f"single-leaf tests {fs[:, 1].sum() / 100 / ft * 100:5.1f} % ({fs[:, 4].sum() / max(1, trips[:, 0].sum()):4.2f} rounds/trip), "
+              f"BVH-top walks {fs[:, 2].sum() / 100 / ft * 100:5.1f} % ({fs[:, 5].sum() / max(1, trips[:, 0].sum()):4.2f} per trip)")
     dr = st[:, 16:25].astype(np.float64)
     drain = end - dry
     order = np.argsort(drain)

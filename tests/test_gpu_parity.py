@@ -1,6 +1,8 @@
 """GPU parity tests proper: the HIP path, called through the C ABI, against the scalar oracle on the same
 seeded inputs.  Bar: BIT-EXACT float32 (north_star allows 1e-4 per channel; the normative arithmetic of
 include/urt_math.h makes equality achievable, so the tests demand it and report the 1e-4 figure too)."""
+import copy
+
 import numpy as np
 import pytest
 
@@ -84,9 +86,11 @@ SCHED_VARIANTS = [
     {"sched_block": 0, "top_nodes": 64, "top_front": -1, "tile_order": 1, "xcd_run": 5},
     {"refill_min": 1, "blas_min": 1, "blas_exit": 1, "shade_min": 1, "waves_per_cu": 3},
     {"refill_min": 64, "blas_min": 64, "blas_exit": 64, "shade_min": 64, "waves_per_cu": 32},
+    {"front_list": 2},                                        # the listed FRONT (the default for this scene is the masked one)
+    {"front_list": 0},                                        # neither: the heap walk with the BVH top inside it
 ]
 SCHED_DEFAULTS = {"sched_block": 0, "top_nodes": 64, "top_front": -1, "lds_tlas": 1, "tile_order": 0, "xcd_run": 0,
-                  "refill_min": 16, "blas_min": 0, "blas_exit": 0, "waves_per_cu": 0, "shade_min": 32}
+                  "refill_min": 16, "blas_min": 0, "blas_exit": 0, "waves_per_cu": 0, "shade_min": 32, "front_list": -1}
 
 
 @pytest.mark.parametrize("variant", range(len(SCHED_VARIANTS)))
@@ -242,3 +246,65 @@ def test_shared_traversal_service_mode5(gpu_ctx):
         for k, v in {"blas_min": 0, "blas_exit": 0, "serve_refill": 16}.items():
             gpu_ctx.set_option(k, v)
         gpu_ctx.set_option("kernel_mode", 3); gpu_ctx.set_option("count_stats", 0)
+
+
+def _heap(nodes):
+    """[(vmin, vmax, index) | None = filler] -> BVHNODE array (RM:148-152; fillers all-zero, index -1: RM:490-494)"""
+    a = np.zeros(len(nodes), scenes.BVHNODE_DT)
+    for i, nd in enumerate(nodes):
+        if nd is None:
+            a[i]["index"] = -1
+        else:
+            a[i]["vmin"], a[i]["vmax"], a[i]["index"] = nd
+    return a
+
+
+def test_masked_front_on_odd_object_heaps(gpu_ctx):
+    """The masked FRONT derives the reference's object-level walk (RS:294-326) from one slab-test bit per heap node.  Heaps the
+    reference's builder never makes but its shader would walk all the same: a buffer that is not a complete tree, a leaf high up
+    beside a deep subtree, a hit leaf whose object id is out of range (it still sets the never-reset `tests` flag, A.5), filler
+    nodes below leaves, an interior node with empty bounds, 16 MeshObjects in a 31-node heap (more than the listed form's 12).
+    Pixels AND traversal counters must equal the oracle's literal walk, for the masked, the listed and the plain FRONT."""
+    rng = scenes.SplitMix64(0x0DD)
+    b = scenes.MeshSceneBuilder()
+    shapes = []
+    for k in range(16):
+        if k % 4 == 3:
+            s_ = 0.8 + 0.4 * rng.value()
+            v, t = scenes.quad((-s_, 0, 0), (s_, 0, 0), (s_, 2 * s_, 0), (-s_, 2 * s_, 0))
+        else:
+            v, t = scenes.icosphere(1 if k % 2 else 0, bumps=0.1)
+        x, z = (k % 4 - 1.5) * 2.2 + 0.5 * (rng.value() - 0.5), (k // 4) * 2.4 - 2.0
+        b.add(v, t, scenes.trs(translate=(x, 0.2 + 0.9 * rng.value(), z), scale=0.6 + 0.5 * rng.value(), yaw_deg=360.0 * rng.value()),
+              scenes._params((rng.value(), rng.value(), rng.value()), (0.1, 0.1, 0.1), (1.5, 1.2, 0.8) if k == 5 else (0, 0, 0), rng.value()))
+    mo, vv, ii, nn, bvh16 = b.finish()
+    lo, hi = scenes.mesh_bounds(mo, vv, ii)
+    box = lambda ks: (lo[list(ks)].min(axis=0), hi[list(ks)].max(axis=0))
+    leaf = lambda k: (lo[k], hi[k], k)
+    inner = lambda ks: box(ks) + (-1,)
+    every = range(16)
+    heaps = {
+        "builder, 16 objects / 31 nodes": bvh16,
+        "5 nodes (not a complete tree), leaf beside a subtree": _heap([inner(every), inner((0, 1)), leaf(2), leaf(0), leaf(1)]),
+        "out-of-range id sets `tests`, fillers under leaves": _heap([inner(every), inner((3, 4)), (lo[5], hi[5], 99), leaf(3), leaf(4), None, None]),
+        "empty interior node, deep left spine": _heap([inner(every), inner(every), (lo[6], lo[6], -1), inner((7, 8, 9)), leaf(10), None, None,
+                                                       inner((7, 8)), leaf(9), None, None, None, None, None, None, leaf(7), leaf(8)]),
+        "single leaf": _heap([leaf(11)]),
+    }
+    base = scenes.Scene("odd-heaps", 144, 88, 4, 1, mesh_objects=mo, vertices=vv, indices=ii, normals=nn, mesh_bvh=bvh16, sky=scenes.make_sky(64, 32))
+    base = base.resized(144, 88, position=(0.3, 3.5, -9.0), fov_deg=70.0)
+    try:
+        for name, heap in heaps.items():
+            sc = copy.copy(base)
+            sc.mesh_bvh = heap
+            o = oracle_for(sc)
+            ref, oc = o.render(mode=1, threads=8, counters=True)
+            for fl in (-1, 2, 0):
+                gpu_ctx.set_option("front_list", fl)
+                gpu, _, gc = render_gpu(gpu_ctx, sc, 3, count=True)
+                assert_same(gpu, ref, f"{name}, front_list {fl}")
+                for k in ("rays", "tlas_nodes", "blas_nodes", "tri_tests", "hit_tri", "hit_ground", "hit_sky"):
+                    assert gc[k] == oc[k], (name, fl, k, gc[k], oc[k])
+                assert gc["watchdog_trips"] == 0
+    finally:
+        gpu_ctx.set_option("front_list", -1)

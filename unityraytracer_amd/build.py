@@ -27,6 +27,37 @@ def _newer(target: str, deps) -> bool:
     return all(os.path.getmtime(d) <= t for d in deps)
 
 
+def build_variant(out: str, defines, verbose: bool = False) -> str:
+    """An A/B or diagnostic build of the same sources with extra -D flags (e.g. URT_STAMPS, URT_SCHED_OCC=4) -> `out`
+    (objects under unityraytracer_amd/build/<name of out>/).  Used through URT_LIB_PATH by scripts/sweep.py --libs and scripts/stamps*.py."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    objdir = os.path.join(_HERE, "build", os.path.splitext(os.path.basename(out))[0])
+    os.makedirs(objdir, exist_ok=True)
+    cflags = [f for f in HIPCC_FLAGS if f != "-shared"] + list(defines)
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    base = os.path.join(_HERE, "build")
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True, cwd=_HERE)
+
+    objs, jobs = [], []
+    for src in srcs:
+        name = os.path.basename(src)
+        if name in ("kernels.hip", "context.cpp") or not os.path.exists(os.path.join(base, name + ".o")):   # the rest does not depend on the defines
+            obj = os.path.join(objdir, name + ".o")
+            jobs.append([hipcc] + cflags + ["-c", src, "-o", obj])
+        else:
+            obj = os.path.join(base, name + ".o")
+        objs.append(obj)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, jobs))
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fvisibility=hidden", "-pthread", "-o", out] + objs)
+    return out
+
+
 def build_library(force: bool = False, verbose: bool = False) -> str:
     """hipcc --offload-arch=gfx950 ... -> unityraytracer_amd/libunityraytracer_amd.so (cross-compiles without a GPU).
     One object per source under unityraytracer_amd/build/ (compiled in parallel, reused while newer than its source and every
@@ -60,4 +91,8 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build_library(force=True, verbose=True))
+    import sys
+    if len(sys.argv) > 2:                                   # python -m unityraytracer_amd.build out.so -DURT_STAMPS ...
+        print(build_variant(os.path.abspath(sys.argv[1]), sys.argv[2:], verbose=True))
+    else:
+        print(build_library(force=len(sys.argv) > 1 and sys.argv[1] == "--force", verbose=True))

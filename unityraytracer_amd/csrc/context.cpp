@@ -8,6 +8,7 @@
 // There is deliberately no CPU path: without a HIP device context creation fails.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -134,6 +135,7 @@ struct urt_context {
   int opt_blas_builder = 0;                 // 0 = binned SAH on host threads (best trees), 1 = LBVH built on the GPU (dynamic scenes)
   float last_prepare_ms = 0;                // host wall time of the last scene preparation (buffers -> device scene)
   int n_scene_tris = 0;                     // triangles of the prepared scene
+  int walk_f4 = 0;                          // float4s of the masked-walk table behind the mesh heap's device copy (0 = none: heap > 31 nodes)
   int scene_max_depth = 0;
   int opt_frames_per_launch = 0;            // 0 = auto (own stream: 64 frames per launch, fewer when the Result slots would exceed 8 GiB; caller's stream: 1), 1 = off, 2..64
   uint64_t scene_epoch = 0;                 // bumps at every scene preparation
@@ -262,6 +264,78 @@ void pack_material(const urt_RayTraceParams& m, float* dst) {
 
 int heap_levels(int n) { int l = 0; while (n > 0) { l++; n >>= 1; } return l; }   // floor(log2 n) + 1
 
+// "Masked" object-level walk (kernels.hip front_masked): for a mesh heap of <= 31 nodes the walk RS:294-326 is evaluated without
+// a stack.  Which nodes a ray pops depends only on the slab tests of their ancestors, and the pop order (children pushed 2i+1
+// then 2i+2, so the right child is popped first) is a static pre-order of the heap.  The heap is therefore re-indexed in that
+// order ("position"): the right child of the node at position p sits at p + 1, the left child at p + 2^(h-1), h = levels below and
+// including p.  One bit per position: H = slab test passed, P = popped (root; children of a popped, hit, interior node — a shift
+// per level), objects to test = popped leaves from the first popped-and-hit leaf on (`tests` is never reset, A.5), in position
+// order = pop order.  The table appended to the device copy of the heap (float4 units; layout shared with kernels.hip):
+//   [0]  n_eval, levels, interior mask, exist mask          [1] leaf_any mask, leaf_valid mask, 0, 0
+//   [2]  depth masks d = 0..3                                [3] left-child shifts d = 0..3
+//   [4 .. 20)  per position p = 0..31: int2 {triangle-BVH root of the MeshObject, first triangle in the LDS copy of the single-leaf
+//              MeshObjects or -1}
+//   [20 .. 20 + 2 * n_eval)  the nodes whose slab test can matter (inside the buffer, non-empty bounds, every ancestor an interior
+//              non-empty node), in position order: vmin.xyz, position bit of the parent (0 = root) | vmax.xyz, position bit
+constexpr int kWalkHeaderF4 = 20;
+bool build_walk_table(const Buffer* heap, int n_meshes, const std::vector<int32_t>& mesh_root, const std::vector<int32_t>& small_first,
+                      std::vector<float>& out) {
+  out.clear();
+  if (!heap || heap->count < 1 || heap->count > 31) return false;
+  const int n = heap->count, D = heap_levels(n);            // complete tree of D levels holds the array
+  const int N = (1 << D) - 1;
+  std::vector<int> pos((size_t)N, -1), depth((size_t)N, 0);
+  {   // right-first pre-order positions of the complete tree's slots
+    std::vector<int> stack{0};
+    int next = 0;
+    while (!stack.empty()) {
+      int i = stack.back(); stack.pop_back();
+      pos[(size_t)i] = next++;
+      if (2 * i + 2 < N) { depth[(size_t)(2 * i + 1)] = depth[(size_t)(2 * i + 2)] = depth[(size_t)i] + 1; stack.push_back(2 * i + 1); stack.push_back(2 * i + 2); }
+    }
+  }
+  auto node = [&](int i) { urt_BVHNode nd; std::memcpy(&nd, heap->host.data() + (size_t)i * URT_STRIDE_BVHNODE, sizeof nd); return nd; };
+  uint32_t imask = 0, exist = 0, leaf_any = 0, leaf_valid = 0, dm[4] = {0, 0, 0, 0};
+  int32_t ls[4] = {0, 0, 0, 0};
+  std::vector<int32_t> pos_tab(64, 0);
+  for (int p = 0; p < 32; p++) { pos_tab[(size_t)(2 * p)] = (int32_t)0x80000000; pos_tab[(size_t)(2 * p + 1)] = -1; }   // empty root
+  std::vector<char> live((size_t)N, 0);                      // slab test can matter
+  struct Ev { int p, parent_p; urt_BVHNode nd; };
+  std::vector<Ev> ev;
+  for (int i = 0; i < N; i++) {
+    const int p = pos[(size_t)i], d = depth[(size_t)i];
+    if (d < D - 1 && d < 4) { dm[d] |= 1u << p; ls[d] = 1 << (D - d - 1); }
+    if (i >= n) continue;
+    urt_BVHNode nd = node(i);
+    exist |= 1u << p;
+    if (nd.index < 0) imask |= 1u << p; else leaf_any |= 1u << p;
+    bool nonempty = !(nd.vmin[0] == nd.vmax[0] && nd.vmin[1] == nd.vmax[1] && nd.vmin[2] == nd.vmax[2]);      // RS:273
+    bool parent_ok = i == 0 || (live[(size_t)((i - 1) / 2)] && node((i - 1) / 2).index < 0);
+    live[(size_t)i] = nonempty && parent_ok;
+    if (nd.index >= 0 && nd.index < n_meshes && mesh_root[(size_t)nd.index] != (int32_t)0x80000000) {
+      leaf_valid |= 1u << p;
+      pos_tab[(size_t)(2 * p)] = mesh_root[(size_t)nd.index];
+      pos_tab[(size_t)(2 * p + 1)] = small_first.empty() ? -1 : small_first[(size_t)nd.index];
+    }
+    if (live[(size_t)i]) ev.push_back(Ev{p, i == 0 ? -1 : pos[(size_t)((i - 1) / 2)], nd});
+  }
+  std::sort(ev.begin(), ev.end(), [](const Ev& a, const Ev& b) { return a.p < b.p; });
+  out.assign((size_t)(kWalkHeaderF4 + 2 * ev.size()) * 4, 0.0f);
+  auto put = [&](size_t word, int32_t v) { std::memcpy(&out[word], &v, 4); };
+  put(0, (int32_t)ev.size()); put(1, D); put(2, (int32_t)imask); put(3, (int32_t)exist);
+  put(4, (int32_t)leaf_any); put(5, (int32_t)leaf_valid);
+  for (int d = 0; d < 4; d++) { put(8 + (size_t)d, (int32_t)dm[d]); put(12 + (size_t)d, ls[d]); }
+  for (size_t k = 0; k < 64; k++) put(16 + k, pos_tab[k]);
+  for (size_t e = 0; e < ev.size(); e++) {
+    float* o = out.data() + (size_t)(kWalkHeaderF4 + 2 * e) * 4;
+    o[0] = ev[e].nd.vmin[0]; o[1] = ev[e].nd.vmin[1]; o[2] = ev[e].nd.vmin[2];
+    int32_t pbit = ev[e].parent_p < 0 ? 0 : (int32_t)(1u << ev[e].parent_p); std::memcpy(&o[3], &pbit, 4);
+    o[4] = ev[e].nd.vmax[0]; o[5] = ev[e].nd.vmax[1]; o[6] = ev[e].nd.vmax[2];
+    int32_t bit = (int32_t)(1u << ev[e].p); std::memcpy(&o[7], &bit, 4);
+  }
+  return true;
+}
+
 void pack_tlas(const Buffer* b, std::vector<float>& out) {
   out.clear();
   if (!b) return;
@@ -300,7 +374,7 @@ int prepare_scene(urt_context* ctx) {
   }
   // meshes: the triangle BVH ("BLAS") of every MeshObject, by the host SAH builder or by the GPU LBVH builder
   auto t_begin = std::chrono::steady_clock::now();
-  std::vector<int32_t> mesh_root_host;
+  std::vector<int32_t> mesh_root_host, small_first;
   int blas_max_depth = 0;
   size_t n_blas_nodes = 0, n_tris = 0;
   if (n_meshes > 0) {
@@ -357,7 +431,7 @@ int prepare_scene(urt_context* ctx) {
       mesh_root_host = blas.mesh_root; blas_max_depth = blas.max_depth; n_blas_nodes = blas.nodes.size() / kBlasNodeFloats; n_tris = blas.tri_slot.size();
     }
     {   // single-leaf MeshObjects: where their triangles sit in the LDS copy (kernels.hip k_sched prologue)
-      std::vector<int32_t> small_first((size_t)n_meshes, -1);
+      small_first.assign((size_t)n_meshes, -1);
       int n_small = 0;
       for (int m = 0; m < n_meshes; m++) {
         int32_t r = mesh_root_host[(size_t)m];
@@ -366,7 +440,8 @@ int prepare_scene(urt_context* ctx) {
       if (n_small > 0 && n_small <= 64) {
         if ((rc = upload(ctx, small_first, &p))) return rc;
         S.mesh_small_first = (const int32_t*)p; S.n_small = n_small;
-      }
+      } else small_first.assign((size_t)n_meshes, -1);
+
     }
   }
   S.n_meshes = n_meshes;
@@ -392,6 +467,14 @@ int prepare_scene(urt_context* ctx) {
   std::vector<float> t;
   const float4* p;
   pack_tlas(bmt, t);
+  ctx->walk_f4 = 0;
+  {   // the masked-walk table of a small mesh heap rides behind the heap's device copy (kernels.hip front_masked)
+    std::vector<float> walk;
+    if (n_meshes > 0 && build_walk_table(bmt, n_meshes, mesh_root_host, small_first, walk)) {
+      ctx->walk_f4 = (int)(walk.size() / 4);
+      t.insert(t.end(), walk.begin(), walk.end());
+    }
+  }
   if ((rc = upload(ctx, t, &p))) return rc; S.mesh_tlas = p; S.n_mesh_tlas = bmt ? bmt->count : 0;
   pack_tlas(bst, t);
   if ((rc = upload(ctx, t, &p))) return rc; S.sphere_tlas = p; S.n_sphere_tlas = bst ? bst->count : 0;
@@ -547,6 +630,14 @@ int configure_sched(urt_context* ctx, const DevScene& S, FrameParams& P, bool to
   // listed FRONT (kernels.hip front_listed): scenes of a few MeshObjects whose heap is in LDS; the list of objects a ray has to test
   // (<= 12 ids of 5 bits) lives in the first two entries of the lane's object-level stack, so it costs no LDS
   bool listed = top_in_front && P.top_nodes > 0 && P.lds_mesh && S.n_meshes <= 12 && ctx->opt_front_list != 0;
+  // masked FRONT (kernels.hip front_masked): mesh heaps of <= 31 nodes are walked with mask arithmetic instead of a stack; the walk
+  // table takes the heap's place in LDS.  "front_list" 2 forces the listed form (A/B), -1 / 1 prefer the masked one.
+  bool masked = top_in_front && P.top_nodes > 0 && ctx->opt_lds_tlas && ctx->walk_f4 > 0 && !P.serve && ctx->opt_front_list != 0 && ctx->opt_front_list != 2;
+  if (masked) {
+    FrameParams Q = P;
+    Q.lds_mesh = 0; Q.walk_f4 = ctx->walk_f4; Q.lds_small = S.n_small > 0;
+    if (sched_lds_bytes(S, Q) * groups <= budget) { P = Q; return 3; }
+  }
   return listed ? 2 : (top_in_front && P.top_nodes > 0) ? 1 : 0;
 }
 
@@ -1325,7 +1416,7 @@ int urt_set_option(urt_context* ctx, const char* name, int value) {
     if (value < 1 || value > 64) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "shade_min must be in [1, 64]");
     ctx->opt_shade_min = value;
   } else if (std::strcmp(name, "front_list") == 0) {
-    if (value < -1 || value > 1) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "front_list must be -1 (auto), 0 or 1");
+    if (value < -1 || value > 2) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "front_list must be -1 (auto), 0, 1 or 2");
     ctx->opt_front_list = value;
   } else if (std::strcmp(name, "shade_split") == 0) {
     if (value < -1 || value > 1) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "shade_split must be -1 (auto), 0 or 1");

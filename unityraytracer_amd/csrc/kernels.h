@@ -16,7 +16,8 @@ hipError_t launch_persist(const DevScene& S, const FrameParams& P, float4* resul
 // mode 3: persistent waves whose lanes are scheduled by phase (FRONT / BLAS / SHADE) inside the wave
 // One launch traces P.n_frames consecutive frames (uniforms: T[0 .. n_frames) in DEVICE memory, Result images P.frame_stride apart from `result`).
 // front_mode: 0 = rays enter a triangle BVH through the BLAS phase only, 1 = they first walk its LDS-resident top inside FRONT,
-// 2 = listed form of 1 (needs P.lds_mesh and n_meshes <= 12)
+// 2 = listed form of 1 (needs P.lds_mesh and n_meshes <= 12), 3 = masked form of 2 (mesh heap of <= 31 nodes: P.walk_f4 float4s of walk
+// table behind S.mesh_tlas, P.lds_mesh = 0; kernels.hip front_masked)
 hipError_t launch_sched(const DevScene& S, const FrameParams& P, const FrameUniforms* T, float4* result, DevCounters* ctr,
                         unsigned int* next, int n_blocks, int front_mode, bool count, hipStream_t st);
 // mode 5: mode 3 with the triangle-BVH phase as a service shared by the 4 waves of a workgroup (k_serve); `mail` = 2 float4 per

@@ -869,10 +869,20 @@ __device__ __forceinline__ int list_get(const int* tl, int j) {
 // trip (a fresh ray whose heap walk was put off: fresh rays walk the heap together, when at least 16 of them wait or when no
 // resumed ray needs the trip — resumed rays are the majority in scenes where a ray meets several big meshes, and a walk for a
 // few fresh lanes would hold all of them up).
+#ifdef URT_STAMPS
+#define URT_FS_DECL , unsigned long long* fs
+#define URT_FS_ARG , fs_arr
+#define URT_FS(stmt) stmt
+#else
+#define URT_FS_DECL
+#define URT_FS_ARG
+#define URT_FS(stmt)
+#endif
 template <bool COUNT>
 __device__ __forceinline__ int front_listed(const DevScene& S, const FrameParams& P, bool mine, bool fresh, v3 o, v3 d, HitRec& best, int& cs,
                                             int* tl, int32_t& cur, LocalCounters& lc, const FrontLds& L, const float4* top, int* bl, int& sp,
-                                            unsigned int& wave_rays) {
+                                            unsigned int& wave_rays URT_FS_DECL) {
+  URT_FS(unsigned long long fs_t0 = wall_clock64();)
   int remaining = cs & 0xff, cursor = cs >> 8;
   const int n_fresh = __popcll(wballot(mine && fresh)), n_resumed = __popcll(wballot(mine && !fresh));
   const bool walk_now = n_fresh >= 16 || n_resumed == 0;
@@ -910,16 +920,19 @@ __device__ __forceinline__ int front_listed(const DevScene& S, const FrameParams
     tl[0] = (int)l0; tl[64] = (int)l1;                       // the walk's stack is dead: its first two entries keep the list
     remaining = count; cursor = 0;
   }
+  URT_FS(if (walk_now && n_fresh > 0) { fs[0] += wall_clock64() - fs_t0; fs[3]++; fs[6] += (unsigned long long)n_fresh; })
   bool need = false;
   bool has = mine && remaining > 0;
   for (;;) {
     // (1) every lane works off the single-leaf MeshObjects (<= 8 triangles: wall quads, planes) at the head of its list:
     //     one cheap body for all of them, until every lane's next entry is a big MeshObject (or its list is done)
     int obj = 0; int32_t root = kEmptyMeshRoot;
+    URT_FS(unsigned long long fs_t1 = wall_clock64();)
     for (;;) {
       if (has) { obj = list_get(tl, cursor); root = L.mesh_root[obj]; }
       bool small = has && root < 0;
       if (wballot(small) == 0) break;
+      URT_FS(fs[4]++;)
       if (small) {
         int bi_local = -1;
         if (L.small_tris) test_leaf<COUNT>(S, root, o, d, best, bi_local, lc, L.small_tris, L.small_first[obj]);
@@ -929,7 +942,9 @@ __device__ __forceinline__ int front_listed(const DevScene& S, const FrameParams
     }
     // (2) ONE walk of the LDS-resident BVH top for all the lanes that now stand at a big MeshObject: the expensive body runs with
     //     as many lanes as the wave can muster, as often as the longest list has big entries
+    URT_FS(fs[1] += wall_clock64() - fs_t1; fs_t1 = wall_clock64();)
     if (wballot(has) == 0) break;
+    URT_FS(fs[5]++;)
     if (has) {
       sp = 0;
       if (root < P.top_nodes) {
@@ -940,8 +955,135 @@ __device__ __forceinline__ int front_listed(const DevScene& S, const FrameParams
       if (root == kBlasDone) has = remaining > 0;           // nothing of this mesh is near the ray
       else { cur = root; need = true; has = false; }         // on to the BLAS phase; the list continues at RESUME
     }
+    URT_FS(fs[2] += wall_clock64() - fs_t1;)
   }
   cs = remaining | (cursor << 8);
+  if (mine && !need && S.n_spheres > 0) {                    // IntersectSphereBVH RS:329-361
+    v3 rcp = mk3(1.0f / (d.x + kEPSILON), 1.0f / (d.y + kEPSILON), 1.0f / (d.z + kEPSILON));
+    int c2 = 1; tl[0] = 0; bool seen2 = false;
+    while (c2 > 0) {
+      c2--;
+      int bi = tl[c2 * 64];
+      bool hit = false; int index = -1;
+      if (bi < S.n_sphere_tlas) {
+        if (COUNT) lc.tlas_nodes++;
+        float4 a, b;
+        if (L.sphere_tlas) { a = L.sphere_tlas[2 * bi]; b = L.sphere_tlas[2 * bi + 1]; } else { a = S.sphere_tlas[2 * bi]; b = S.sphere_tlas[2 * bi + 1]; }
+        index = as_int(a.w);
+        hit = tlas_slab(a, b, o, rcp);
+      }
+      if (hit) {
+        if (index < 0) { tl[c2 * 64] = bi * 2 + 1; c2++; tl[c2 * 64] = bi * 2 + 2; c2++; }
+        else seen2 = true;
+      }
+      if (seen2 && index >= 0 && index < S.n_spheres) intersect_sphere<COUNT>(S, index, o, d, best, lc, L.sphere_pr);
+    }
+  }
+  return put_off ? 2 : need ? 1 : 0;
+}
+
+// FRONT for multi-mesh scenes, "masked" form (front mode 3): front_listed without the divergent heap walk and without the list.
+// For a mesh heap of <= 31 nodes the object-level walk (RS:294-326) is a function of one bit per node — did the ray pass the node's
+// slab test (RS:271-291; it never looks at the best hit so far) — and of the heap's static shape.  The nodes are kept in POP
+// order (right-first pre-order: children are pushed 2i+1 then 2i+2, so the right child is popped first): the right child of the
+// node at position p sits at p + 1, the left child at p + 2^(levels below p).  A fresh ray evaluates the slab test of every node
+// whose outcome can matter (wave-uniform loop, bounds broadcast from LDS, no stack, no divergence), then derives with a few
+// mask operations
+//     P = popped nodes: the root, and level by level the children of popped, hit, interior nodes (two shifts per level),
+//     T = the MeshObjects to test: popped leaves from the first popped-AND-hit leaf on in pop order (`tests` is never reset: A.5),
+// and keeps T in one register: bit order = the reference's test order.  The wave then works the masks off exactly as front_listed
+// works its lists off (inline triangle tests for lanes at a single-leaf MeshObject, one BVH-top walk for lanes at a big one).
+// W = the walk table in LDS (context.cpp build_walk_table).  cs = T.  Returns 0 / 1 / 2 like front_listed.
+struct WalkLds {
+  const int* hdr = nullptr;            // [0] n_eval, levels, interior mask, exist mask  [4] leaf_any, leaf_valid  [8..11] depth masks  [12..15] left-child shifts
+  const int* pos_tab = nullptr;        // [2p] triangle-BVH root of the object at position p, [2p+1] its first triangle in small_tris or -1
+  const float4* eval = nullptr;        // [2e] vmin.xyz, position bit of the parent (0: the root)  [2e+1] vmax.xyz, position bit
+};
+template <bool COUNT>
+__device__ __forceinline__ int front_masked(const DevScene& S, const FrameParams& P, bool mine, bool fresh, v3 o, v3 d, HitRec& best, int& cs,
+                                            int* tl, int32_t& cur, LocalCounters& lc, const FrontLds& L, const WalkLds& W, const float4* top, int* bl, int& sp,
+                                            unsigned int& wave_rays URT_FS_DECL) {
+  URT_FS(unsigned long long fs_t0 = wall_clock64();)
+  unsigned int T = (unsigned int)cs;
+  const int n_fresh = __popcll(wballot(mine && fresh)), n_resumed = __popcll(wballot(mine && !fresh));
+  const bool walk_now = n_fresh >= 16 || n_resumed == 0;
+  if (!walk_now) mine = mine && !fresh;
+  else wave_rays += (unsigned int)n_fresh;                  // Trace() invocations (RS:454), counted per wave
+  const bool put_off = !walk_now && fresh;
+  if (walk_now && n_fresh > 0) {                             // (wave-uniform: the loop below runs on scalar control flow)
+    const bool walker = mine && fresh;
+    if (walker) {
+      best.t = URT_INF; best.kid = 0; best.u = 0; best.v = 0;
+      float t = -o.y / d.y;                                 // IntersectGroundPlane RS:156-172
+      if (t > 0 && t < best.t) { best.t = t; best.kid = 1; }
+    }
+    v3 rcp = mk3(1.0f / (d.x + kEPSILON), 1.0f / (d.y + kEPSILON), 1.0f / (d.z + kEPSILON));
+    unsigned int H = 0;
+    const int n_eval = __builtin_amdgcn_readfirstlane(W.hdr[0]);
+    if (walker) for (int e = 0; e < n_eval; e++) {           // the slab tests that can matter, bounds broadcast from LDS
+      float4 a = W.eval[2 * e], b = W.eval[2 * e + 1];
+      // a node whose parent no ray of this wave passed is popped by none of them: skipped for the whole wave (pre-order: the parent's
+      // bit is final by now).  Sparse scenes (C5: 4.6 of 31 nodes popped per ray) keep the cost of the stack walk, dense ones lose nothing.
+      const unsigned int pbit = (unsigned int)as_int(a.w);
+      if (pbit != 0u && wballot((H & pbit) != 0u) == 0) continue;
+      float t_min = -kFLOAT_MAX, t_max = kFLOAT_MAX;         // tlas_slab without the empty-node test (empty nodes are not in the table)
+      float t1 = (a.x - o.x) * rcp.x, t2 = (b.x - o.x) * rcp.x;
+      t_min = f_max(t_min, f_min(t1, t2)); t_max = f_min(t_max, f_max(t1, t2));
+      t1 = (a.y - o.y) * rcp.y; t2 = (b.y - o.y) * rcp.y;
+      t_min = f_max(t_min, f_min(t1, t2)); t_max = f_min(t_max, f_max(t1, t2));
+      t1 = (a.z - o.z) * rcp.z; t2 = (b.z - o.z) * rcp.z;
+      t_min = f_max(t_min, f_min(t1, t2)); t_max = f_min(t_max, f_max(t1, t2));
+      H |= t_max >= t_min ? (unsigned int)as_int(b.w) : 0u;
+    }
+    const unsigned int imask = (unsigned int)W.hdr[2];
+    const int levels = __builtin_amdgcn_readfirstlane(W.hdr[1]);
+    unsigned int Pm = 1u;                                    // popped: the root ...
+    for (int dpt = 0; dpt + 1 < levels && dpt < 4; dpt++) {  // ... and the children of popped, hit, interior nodes, level by level
+      unsigned int X = Pm & H & imask & (unsigned int)W.hdr[8 + dpt];
+      Pm |= (X << 1) | (X << W.hdr[12 + dpt]);
+    }
+    if (COUNT && walker) lc.tlas_nodes += (unsigned int)__popc(Pm & (unsigned int)W.hdr[3]);     // BVHNode fetches of the reference's walk (bi < count)
+    unsigned int src = Pm & H & (unsigned int)W.hdr[4];      // popped and hit leaves: the first one sets `tests` (RS:315), for good
+    unsigned int Tn = 0;
+    if (src) Tn = Pm & (unsigned int)W.hdr[5] & ~((1u << __builtin_ctz(src)) - 1u);
+    if (walker) T = Tn;
+  }
+  URT_FS(if (walk_now && n_fresh > 0) { fs[0] += wall_clock64() - fs_t0; fs[3]++; fs[6] += (unsigned long long)n_fresh; })
+  bool need = false;
+  bool has = mine && T != 0;
+  for (;;) {
+    // (1) every lane works off the single-leaf MeshObjects at the head of its mask, until every lane stands at a big one (or is done)
+    int32_t root = kEmptyMeshRoot; int sfirst = -1;
+    URT_FS(unsigned long long fs_t1 = wall_clock64();)
+    for (;;) {
+      if (has) { int p = __builtin_ctz(T); root = W.pos_tab[2 * p]; sfirst = W.pos_tab[2 * p + 1]; }
+      bool small = has && root < 0;
+      if (wballot(small) == 0) break;
+      URT_FS(fs[4]++;)
+      if (small) {
+        int bi_local = -1;
+        if (L.small_tris) test_leaf<COUNT>(S, root, o, d, best, bi_local, lc, L.small_tris, sfirst);
+        else test_leaf<COUNT>(S, root, o, d, best, bi_local, lc);
+        T &= T - 1u; has = T != 0;
+      }
+    }
+    URT_FS(fs[1] += wall_clock64() - fs_t1; fs_t1 = wall_clock64();)
+    // (2) ONE walk of the LDS-resident BVH top for all the lanes that now stand at a big MeshObject
+    if (wballot(has) == 0) break;
+    URT_FS(fs[5]++;)
+    if (has) {
+      sp = 0;
+      if (root < P.top_nodes) {
+        BlasRay R = blas_ray(o, d);
+        do root = blas_node_step_top<COUNT>(top, root, R, best.t, bl, sp, lc); while (root >= 0 && root < P.top_nodes);
+      }
+      T &= T - 1u;
+      if (root == kBlasDone) has = T != 0;                   // nothing of this mesh is near the ray
+      else { cur = root; need = true; has = false; }         // on to the BLAS phase; the mask continues at RESUME
+    }
+    URT_FS(fs[2] += wall_clock64() - fs_t1;)
+  }
+  cs = (int)T;
   if (mine && !need && S.n_spheres > 0) {                    // IntersectSphereBVH RS:329-361
     v3 rcp = mk3(1.0f / (d.x + kEPSILON), 1.0f / (d.y + kEPSILON), 1.0f / (d.z + kEPSILON));
     int c2 = 1; tl[0] = 0; bool seen2 = false;
@@ -1030,6 +1172,23 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
       L.small_tris = lds4 + at; at += 3 * S.n_small;
     }
   }
+  WalkLds W;
+  if (FMODE == 3) {                                             // masked FRONT: the walk table instead of the heap (front_masked)
+    const float4* wsrc = S.mesh_tlas + 2 * S.n_mesh_tlas;
+    for (int i = threadIdx.x; i < P.walk_f4; i += blockDim.x) lds4[at + i] = wsrc[i];
+    W.hdr = (const int*)(lds4 + at); W.pos_tab = W.hdr + 16; W.eval = lds4 + at + 20; at += P.walk_f4;
+    if (P.lds_small) {                                          // triangle records of the single-leaf MeshObjects
+      for (int m = threadIdx.x; m < S.n_meshes; m += blockDim.x) {
+        int sf = S.mesh_small_first[m];
+        if (sf >= 0) {
+          uint32_t code = ~(uint32_t)S.mesh_root[m];
+          uint32_t first = code >> 3, cnt = (code & 7u) + 1u;
+          for (uint32_t q = 0; q < 3 * cnt; q++) lds4[at + 3 * sf + q] = S.tri_verts[3 * (size_t)first + q];
+        }
+      }
+      L.small_tris = lds4 + at; at += 3 * S.n_small;
+    }
+  }
   if (P.lds_sphere) {                                           // object-level sphere heap + sphere positions/radii
     for (int i = threadIdx.x; i < 2 * S.n_sphere_tlas; i += blockDim.x) lds4[at + i] = S.sphere_tlas[i];
     L.sphere_tlas = lds4 + at; at += 2 * S.n_sphere_tlas;
@@ -1065,6 +1224,7 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
   unsigned long long t_begin = wall_clock64(), t_dry = 0;
   unsigned long long c_begin = __builtin_amdgcn_s_memtime();
   unsigned long long dr_trips[4] = {0, 0, 0, 0}, dr_t[3] = {0, 0, 0}, dr_live = 0, dr_lanes3 = 0;   // after the work ran dry
+  unsigned long long fs_arr[7] = {0, 0, 0, 0, 0, 0, 0};   // listed FRONT: time in the heap walk / single-leaf tests / BVH-top walks, walks, single-leaf rounds, top walks, fresh lanes walked
 #endif
 
   for (;;) {
@@ -1130,10 +1290,11 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
 #endif
     if (phase == ST_FRONT) {
       // ---------------- FRONT / RESUME: Trace() up to the next triangle-BVH visit (RS:364-383) ----------------
-      if (FMODE != 2) wave_rays += (unsigned int)__popcll(wballot(st == ST_FRONT));     // Trace() invocations (RS:454), counted per wave
-      if (FMODE == 2) {
+      if (FMODE < 2) wave_rays += (unsigned int)__popcll(wballot(st == ST_FRONT));     // Trace() invocations (RS:454), counted per wave
+      if (FMODE >= 2) {
         bool mine = st == ST_FRONT || st == ST_RESUME;
-        int r = front_listed<COUNT>(S, P, mine, st == ST_FRONT, o, d, best, cs, tl, cur, lc, L, top, bl, sp, wave_rays);
+        int r = FMODE == 3 ? front_masked<COUNT>(S, P, mine, st == ST_FRONT, o, d, best, cs, tl, cur, lc, L, W, top, bl, sp, wave_rays URT_FS_ARG)
+                           : front_listed<COUNT>(S, P, mine, st == ST_FRONT, o, d, best, cs, tl, cur, lc, L, top, bl, sp, wave_rays URT_FS_ARG);
         if (mine && r != 2) {
           if (r == 1) { best_i = -1; st = ST_BLAS; }
           else st = best.t < URT_INF ? ST_SHADE : ST_SKY;
@@ -1189,7 +1350,7 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
       if (mine) cur = c;
       // back to the heap walk (RS:323-325 continues) — or, when nothing of Trace() is left to do (empty object-level stack and
       // no spheres), straight to shading: saves the path one scheduling round trip per bounce
-      if (mine && cur == kBlasDone) st = ((cs & 0xff) == 0 && S.n_spheres == 0) ? (best.t < URT_INF ? ST_SHADE : ST_SKY) : ST_RESUME;
+      if (mine && cur == kBlasDone) st = ((FMODE == 3 ? cs : (cs & 0xff)) == 0 && S.n_spheres == 0) ? (best.t < URT_INF ? ST_SHADE : ST_SKY) : ST_RESUME;
     } else {
       // ---------------- SHADE + bookkeeping of CSMain's loops (RS:444-468) ----------------
       bool next_ray = false;
@@ -1237,6 +1398,7 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
     sp_[w + 23] = dr_live; sp_[w + 24] = dr_lanes3;
     for (int q = 0; q < 4; q++) { sp_[w + q] = ph_t[q]; sp_[w + 4 + q] = ph_lanes[q]; sp_[w + 8 + q] = ph_trips[q]; }
     sp_[w + 12] = t_begin; sp_[w + 13] = wall_clock64(); sp_[w + 14] = t_dry; sp_[w + 15] = __builtin_amdgcn_s_memtime() - c_begin;
+    for (int q = 0; q < 7; q++) sp_[w + 25 + q] = fs_arr[q];
   }
 #endif
   if (watchdog && (threadIdx.x & 63) == 0) report_watchdog(P, ctr);
@@ -1363,6 +1525,9 @@ __global__ __launch_bounds__(BLOCK, URT_SERVE_OCC) void k_serve(DevScene S, Fram
   unsigned int wave_iters = 0, wave_rays = 0;
   bool watchdog = false;
   unsigned long long sv[6] = {0, 0, 0, 0, 0, 0};   // COUNT: service visits, trips, lane-trips, claim rounds, rays claimed, rays suspended (per wave)
+#ifdef URT_STAMPS
+  unsigned long long fs_arr[7] = {0, 0, 0, 0, 0, 0, 0};
+#endif
 
   for (;;) {
     if (watchdog) break;
@@ -1428,7 +1593,7 @@ __global__ __launch_bounds__(BLOCK, URT_SERVE_OCC) void k_serve(DevScene S, Fram
       if (FMODE != 2) wave_rays += (unsigned int)__popcll(wballot(st == ST_FRONT));
       if (FMODE == 2) {
         bool mine = st == ST_FRONT || st == ST_RESUME;
-        int r = front_listed<COUNT>(S, P, mine, st == ST_FRONT, o, d, best, cs, tl, cur, lc, L, top, bl, sp, wave_rays);
+        int r = front_listed<COUNT>(S, P, mine, st == ST_FRONT, o, d, best, cs, tl, cur, lc, L, top, bl, sp, wave_rays URT_FS_ARG);
         if (mine && r != 2) {
           if (r == 1) need = true;
           else st = best.t < URT_INF ? ST_SHADE : ST_SKY;
@@ -2102,7 +2267,8 @@ hipError_t launch_persist(const DevScene& S, const FrameParams& P, float4* resul
 size_t sched_lds_bytes(const DevScene& S, const FrameParams& P) {
   size_t f4 = (size_t)P.top_nodes * 4;
   if (P.lds_mesh) f4 += 2 * (size_t)S.n_mesh_tlas + ((size_t)S.n_meshes + 3) / 4;
-  if (P.lds_small) f4 += ((size_t)S.n_meshes + 3) / 4 + 3 * (size_t)S.n_small;
+  if (P.walk_f4 > 0) f4 += (size_t)P.walk_f4 + (P.lds_small ? 3 * (size_t)S.n_small : 0);       // masked FRONT: the walk table replaces the heap (lds_mesh = 0)
+  else if (P.lds_small) f4 += ((size_t)S.n_meshes + 3) / 4 + 3 * (size_t)S.n_small;
   if (P.lds_sphere) f4 += 2 * (size_t)S.n_sphere_tlas + (size_t)S.n_spheres;
   if (P.serve) f4 += 2 * (size_t)P.block_threads + 1;          // mode 5: the workgroup's mailbox (k_serve)
   return f4 * 16 + (size_t)(P.tlas_stack + P.blas_stack) * 64 * (size_t)(P.block_threads / 64) * sizeof(int);
@@ -2129,6 +2295,7 @@ static hipError_t launch_sched_m(const DevScene& S, const FrameParams& P, const 
 template <bool COUNT, int BLOCK>
 static hipError_t launch_sched_b(const DevScene& S, const FrameParams& P, const FrameUniforms* T, float4* result, DevCounters* ctr,
                                  unsigned int* next, int n_blocks, size_t lds, int front_mode, hipStream_t st) {
+  if (front_mode == 3) return launch_sched_m<COUNT, BLOCK, 3>(S, P, T, result, ctr, next, n_blocks, lds, st);
   if (front_mode == 2) return launch_sched_m<COUNT, BLOCK, 2>(S, P, T, result, ctr, next, n_blocks, lds, st);
   if (front_mode == 1) return launch_sched_m<COUNT, BLOCK, 1>(S, P, T, result, ctr, next, n_blocks, lds, st);
   return launch_sched_m<COUNT, BLOCK, 0>(S, P, T, result, ctr, next, n_blocks, lds, st);
@@ -2140,6 +2307,8 @@ hipError_t launch_sched(const DevScene& S, const FrameParams& P, const FrameUnif
   if (P.block_threads != 64 && P.block_threads != 256) return hipErrorInvalidValue;   // independent waves; a workgroup shares the LDS top-of-tree copy
   if (P.n_frames < 1 || P.n_frames > kMaxFramesPerLaunch) return hipErrorInvalidValue;
   if (front_mode == 2 && (!P.lds_mesh || S.n_meshes > 12 || P.tlas_stack < 2)) return hipErrorInvalidValue;
+  if (front_mode == 3 && (P.walk_f4 < 20 || P.lds_mesh || P.top_nodes <= 0 || S.n_mesh_tlas > 31)) return hipErrorInvalidValue;
+  if (front_mode != 3 && P.walk_f4 != 0) return hipErrorInvalidValue;
   hipError_t e = hipMemsetAsync(next, 0, kWorkShards * 32 * sizeof(unsigned int), st);
   if (e != hipSuccess) return e;
   size_t lds = sched_lds_bytes(S, P);

@@ -69,6 +69,8 @@ struct FrameParams {
   int top_nodes;            // mode 3: triangle-BVH nodes [0, top_nodes) are copied to LDS (breadth-first top of the forest); 0 = none
   int lds_small;            // mode 3: triangle records of the single-leaf MeshObjects in LDS (needs lds_mesh) (0/1)
   int lds_mesh, lds_sphere; // mode 3: keep the object-level mesh heap + roots / sphere heap + spheres in LDS (0/1)
+  int walk_f4;              // mode 3, masked FRONT (front mode 3): float4s of the walk table behind the mesh heap's device copy, kept in LDS
+                            // instead of the heap itself (context.cpp build_walk_table); 0 = not in use
   int serve;                // mode 5: the traversal phase is a service shared by the waves of a workgroup (kernels.hip k_serve) (0/1)
   int pool_inloop;          // modes 4, 5: idle lanes that trigger a re-feed of the traversal phase from the waiting rays (1..64)
   int pool_other_min;       // mode 4: lanes of FRONT / SHADE work that make those phases worth a trip while rays queue for the BVH
