@@ -75,6 +75,10 @@ def main():
     ap.add_argument("--gather-every", type=int, default=1, help="multi-GPU: gather the accumulated strips to rank 0 after every K-th frame (and after the last); "
                     "1 = the frame-end gather of every frame (default); a gather overwrites the whole image, so K > 1 only lowers the rate at which rank 0 could present it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--clock-warmup-ms", type=float, default=60.0,
+                    help="before the W warm-up steps: run the same step untimed for this long so that the GPU has left its idle clocks "
+                         "(a step is 0.25 ms: W = 5 steps are 1.3 ms of GPU work, far less than the clock governor's reaction time; measured: "
+                         "the 20-frame launch takes 5.2 ms from idle clocks, 4.75 ms after >= 15 ms of load).  Reported as `clock_warmup`; 0 = off")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -239,6 +243,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
+    # ---- clock warm-up (untimed, reported): the step itself, repeated until the GPU has been busy for --clock-warmup-ms ----
+    clock_warmup = {"steps": 0, "ms": 0.0}
+    if args.clock_warmup_ms > 0:
+        tw = time.perf_counter()
+        while (time.perf_counter() - tw) * 1e3 < args.clock_warmup_ms:
+            for _ in range(64):
+                step()
+            drain()
+            fence()
+            clock_warmup["steps"] += 64
+        clock_warmup["ms"] = round((time.perf_counter() - tw) * 1e3, 1)
+        master._frame = 0                      # the W warm-up and K timed steps are frames 0 .. W+K-1 of the documented sequence, as without it
+        master._currentSample = 0              # (sample 0 blends with alpha 1: the accumulation restarts)
     for _ in range(args.warmup):
         step()
     drain()
@@ -364,6 +381,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "present": True,     # the step includes RM:819's Graphics.Blit(_converged, destination) (N > 1: the gather into rank 0's image)
+            "clock_warmup": clock_warmup,   # untimed steps run BEFORE the W warm-up steps to leave idle clocks (--clock-warmup-ms; 0 disables)
             "config": {"workload": f"{args.config}: {scene.name}, {scene.n_triangles} triangles + triangle BVH, {len(scene.spheres)} spheres, "
                                    f"ground plane, equirect sky; numBounces {scene.num_bounces}, numRays {scene.num_rays}",
                        "frame": [width, height], "pixels_per_gpu": width * height // world,

@@ -192,6 +192,7 @@ typedef struct urt_counters {
  *                  "pool_other_min" (1..64),
  *          "blas_leaf_max" (1..8: triangles per BVH leaf; rebuilds the BVH),
  *          "stack_pad" (0..96: test hook, unused extra entries per traversal stack -> the > 64 KiB LDS launch path),
+ *          "refit" (0/1, default 1: moved MeshObjects are refitted on the GPU instead of rebuilt — see urt_debug_refit_stats),
  *          "watchdog_cap" (test hook: scheduler trips a wave may make before it gives up; 0 = auto = 2^24 x frames of the launch x
  *                          max(1, numRays x numBounces / 8))
  *          — tuning knobs; they change speed only, never pixels. */
@@ -321,6 +322,13 @@ URT_API int urt_debug_read_scene_blas(urt_context* ctx, float* nodes, int32_t* t
  * MeshObject's matrix and the positions behind its index slots are unchanged (the reference re-uploads every buffer when
  * any object moves, RM:262-336).  Reports how many MeshObject BVHs were reused / built since the context was created. */
 URT_API int urt_debug_blas_cache_stats(urt_context* ctx, uint64_t* out_reused, uint64_t* out_built);
+/* Dynamic scenes.  When the only buffer CONTENTS that changed since the scene was prepared are those of _MeshObjects, _MeshBVH, _Spheres
+ * and _SphereBVH (same counts, same index range per MeshObject; data equal to what a buffer already holds counts as unchanged — the
+ * reference re-uploads every list when one object moves, RM:215-230 -> 262-336), the device scene is updated in place: materials and
+ * object-level tables are re-packed, and MeshObjects whose localToWorldMatrix changed keep the topology of their triangle BVH — their
+ * triangle records and boxes are recomputed on the GPU (csrc/refit.hip; option "refit" = 0 turns this off).  Reports MeshObjects
+ * refitted and in-place preparations since the context was created. */
+URT_API int urt_debug_refit_stats(urt_context* ctx, uint64_t* out_refitted_meshes, uint64_t* out_incremental_preparations);
 /* kernel_mode 5 with "count_stats" = 1: what the shared traversal service did since the last urt_reset_counters —
  * out6 = visits of the service, its trips, active lanes summed over the trips, claim rounds, rays claimed, rays suspended. */
 URT_API int urt_debug_serve_stats(urt_context* ctx, unsigned long long* out6);

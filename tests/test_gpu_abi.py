@@ -112,6 +112,7 @@ def test_moving_one_mesh_rebuilds_only_its_bvh(gpu_ctx):
     of the MeshObjects that changed only — and the frame is the same as if everything had been rebuilt."""
     from unityraytracer_amd import debug_build_blas
     sc = scenes.mixed_test_scene(96, 64)
+    gpu_ctx.set_option("refit", 0)                            # (the default refits the moved MeshObject on the GPU: tests/test_gpu_refit.py)
     m = RayTraceMaster(gpu_ctx, sc)
     m.OnRenderImage()
     reused0, built0 = gpu_ctx.blas_cache_stats()
@@ -135,6 +136,7 @@ def test_moving_one_mesh_rebuilds_only_its_bvh(gpu_ctx):
     o.set_blas(nodes, tri, root)
     assert bits_equal(m._target.GetPixels(), o.render(mode=1, threads=4))
     m.OnDisable()
+    gpu_ctx.set_option("refit", 1)
 
 
 def test_resize_resets_accumulation_and_external_texture(gpu_ctx):

@@ -130,9 +130,12 @@ def test_c5_scene_preparation_under_10_ms(gpu_ctx):
         m = RayTraceMaster(gpu_ctx, sc)
         m.OnRenderImage()                                        # first preparation also loads the build kernels
         times = []
-        for _ in range(3):
-            m._vertexBuffer.SetData(np.ascontiguousarray(sc.vertices, np.float32))     # any SetData makes the scene stale (RM:250)
+        for k in range(3):
+            v = np.ascontiguousarray(sc.vertices, np.float32).copy()
+            v[0, 0] = np.nextafter(v[0, 0], np.float32(np.inf if k % 2 == 0 else -np.inf))     # new CONTENTS make the scene stale (equal data would not)
+            m._vertexBuffer.SetData(v)
             times.append(gpu_ctx.scene_info()["prepare_ms"])
+        m._vertexBuffer.SetData(np.ascontiguousarray(sc.vertices, np.float32))
         info = gpu_ctx.scene_info()
         img = m._target.GetPixels()
         m.OnDisable()

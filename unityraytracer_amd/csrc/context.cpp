@@ -23,6 +23,7 @@
 #include "blas_builder.h"
 #include "kernels.h"
 #include "lbvh.h"
+#include "refit.h"
 #include "urt_device.h"
 
 #include <chrono>
@@ -82,6 +83,23 @@ struct urt_context {
 
   // derived device scene
   bool scene_dirty = true;
+  // what made it dirty: SetData on a bound buffer sets the slot's bit; anything else (binding changes, options) asks for a full
+  // preparation.  When only _MeshObjects / _MeshBVH / _Spheres / _SphereBVH contents changed, the scene is updated in place
+  // (prepare_incremental: moved MeshObjects are refitted on the GPU, csrc/refit.hip)
+  unsigned int dirty_slots = 0;
+  bool dirty_full = true;
+  int opt_refit = 1;                        // 0 = always prepare from scratch
+  std::vector<uint8_t> prev_mesh_objects;   // the _MeshObjects records of the prepared scene
+  std::vector<int32_t> h_mesh_root, h_small_first;
+  struct RefitAux {                         // device-resident, part of the prepared scene (scene_allocs)
+    const float* vertices = nullptr; const int32_t* indices = nullptr;      // copies of _Vertices / _Indices
+    int32_t* parent = nullptr; int32_t* node_mesh = nullptr; int32_t* depth = nullptr;
+    float4* cbox = nullptr; unsigned int* ext = nullptr;
+    float* matrices = nullptr; int32_t* moved = nullptr;
+    bool ready = false;
+  } refit;
+  size_t cap_materials = 0, cap_mesh_tlas = 0, cap_sphere_tlas = 0, cap_sphere_pr = 0;   // float4 capacities of the arrays updated in place
+  uint64_t refitted_meshes = 0, incremental_preps = 0;
   DevScene ds{};
   std::vector<void*> scene_allocs;
   int tlas_stack = 2, blas_stack = 2;
@@ -210,6 +228,8 @@ void free_scene(urt_context* ctx) {
   for (void* p : ctx->scene_allocs) (void)hipFree(p);
   ctx->scene_allocs.clear();
   ctx->ds = DevScene{};
+  ctx->refit = urt_context::RefitAux{};
+  ctx->cap_materials = ctx->cap_mesh_tlas = ctx->cap_sphere_tlas = ctx->cap_sphere_pr = 0;
 }
 
 template <typename T>
@@ -349,9 +369,115 @@ void pack_tlas(const Buffer* b, std::vector<float>& out) {
   }
 }
 
+// Update a small device array of the prepared scene: in place while it fits its allocation, else a new allocation (the old one
+// stays in scene_allocs until the next full preparation).  The stream has been waited for.
+int update_array(urt_context* ctx, const std::vector<float>& v, const float4** dev, size_t* cap_f4) {
+  size_t need = (v.size() + 3) / 4;
+  if (need == 0) { *dev = nullptr; return URT_OK; }
+  if (*dev && need <= *cap_f4) {
+    URT_HIP(ctx, hipMemcpy(const_cast<float4*>(*dev), v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+    return URT_OK;
+  }
+  int rc = upload(ctx, v, dev);
+  if (rc == URT_OK) *cap_f4 = need;
+  return rc;
+}
+
+bool build_walk_table(const Buffer* heap, int n_meshes, const std::vector<int32_t>& mesh_root, const std::vector<int32_t>& small_first, std::vector<float>& out);
+void pack_tlas(const Buffer* b, std::vector<float>& out);
+
+// The dynamic-scene path (RM:215-230: a moved object makes the reference re-upload every buffer).  When the only contents that changed
+// since the scene was prepared are those of _MeshObjects / _MeshBVH / _Spheres / _SphereBVH — same counts, same index ranges per
+// MeshObject — the device scene is UPDATED: materials, object-level heaps and sphere tables are re-packed (a few KB), and every
+// MeshObject whose localToWorldMatrix changed keeps its triangle BVH's topology: its triangle records and boxes are recomputed on the
+// GPU (csrc/refit.hip).  Returns 1 when the change is not of that kind (the caller prepares from scratch).
+int prepare_incremental(urt_context* ctx) {
+  const unsigned int small = (1u << B_MESHOBJECTS) | (1u << B_MESHBVH) | (1u << B_SPHERES) | (1u << B_SPHEREBVH);
+  if (!ctx->opt_refit || ctx->dirty_full || ctx->scene_allocs.empty() || (ctx->dirty_slots & ~small)) return 1;
+  DevScene& S = ctx->ds;
+  const Buffer* bm = bound_buffer(ctx, B_MESHOBJECTS);
+  const Buffer* bs = bound_buffer(ctx, B_SPHERES);
+  const Buffer* bmt = bound_buffer(ctx, B_MESHBVH);
+  const Buffer* bst = bound_buffer(ctx, B_SPHEREBVH);
+  const int n_meshes = bm ? bm->count : 0, n_spheres = bs ? bs->count : 0;
+  if (n_meshes != S.n_meshes || n_spheres != S.n_spheres) return 1;
+  if ((size_t)n_meshes * URT_STRIDE_MESHOBJECT != ctx->prev_mesh_objects.size()) return 1;
+  auto t_begin = std::chrono::steady_clock::now();
+  std::vector<int32_t> moved((size_t)n_meshes, 0);
+  std::vector<float> matrices((size_t)n_meshes * 16, 0.0f);
+  int n_moved = 0;
+  for (int m = 0; m < n_meshes; m++) {
+    urt_MeshObject a, b;
+    std::memcpy(&a, ctx->prev_mesh_objects.data() + (size_t)m * URT_STRIDE_MESHOBJECT, sizeof a);
+    std::memcpy(&b, bm->host.data() + (size_t)m * URT_STRIDE_MESHOBJECT, sizeof b);
+    if (a.indices_offset != b.indices_offset || a.indices_count != b.indices_count) return 1;
+    std::memcpy(&matrices[(size_t)m * 16], b.localToWorldMatrix, 64);
+    if (std::memcmp(a.localToWorldMatrix, b.localToWorldMatrix, 64) != 0 && b.indices_count >= 3) { moved[(size_t)m] = 1; n_moved++; }
+  }
+  if (n_moved > 0 && (!ctx->refit.ready || ctx->n_scene_tris <= 0)) return 1;
+  URT_HIP(ctx, hipStreamSynchronize(ctx->stream));           // frames in flight read the arrays that are about to change
+  int rc;
+  // materials: spheres, mesh objects, ground plane (pack_material: what Shade derives from the material alone)
+  {
+    std::vector<float> mats((size_t)(n_meshes + n_spheres + 1) * kMatFloats);
+    urt_RayTraceParams ground{};
+    ground.color_albedo[0] = 0.5f; ground.color_albedo[1] = 0.3f; ground.color_albedo[2] = 0.15f; ground.smoothness = 0.3f;
+    pack_material(ground, mats.data() + (size_t)(n_meshes + n_spheres) * kMatFloats);
+    for (int m = 0; m < n_meshes; m++) {
+      urt_MeshObject mo; std::memcpy(&mo, bm->host.data() + (size_t)m * URT_STRIDE_MESHOBJECT, sizeof mo);
+      pack_material(mo.lighting, mats.data() + (size_t)(n_spheres + m) * kMatFloats);
+    }
+    std::vector<float> pr((size_t)n_spheres * 4);
+    for (int i = 0; i < n_spheres; i++) {
+      urt_Sphere sp; std::memcpy(&sp, bs->host.data() + (size_t)i * URT_STRIDE_SPHERE, sizeof sp);
+      pr[4 * (size_t)i] = sp.position[0]; pr[4 * (size_t)i + 1] = sp.position[1]; pr[4 * (size_t)i + 2] = sp.position[2]; pr[4 * (size_t)i + 3] = sp.radius;
+      pack_material(sp.lighting, mats.data() + (size_t)i * kMatFloats);
+    }
+    if ((rc = update_array(ctx, mats, &S.materials, &ctx->cap_materials))) return rc;
+    if (n_spheres > 0 && (rc = update_array(ctx, pr, &S.sphere_pr, &ctx->cap_sphere_pr))) return rc;
+  }
+  // object-level heaps (+ the masked-walk table of a small mesh heap)
+  {
+    std::vector<float> t, walk;
+    pack_tlas(bmt, t);
+    ctx->walk_f4 = 0;
+    if (n_meshes > 0 && build_walk_table(bmt, n_meshes, ctx->h_mesh_root, ctx->h_small_first, walk)) {
+      ctx->walk_f4 = (int)(walk.size() / 4);
+      t.insert(t.end(), walk.begin(), walk.end());
+    }
+    if ((rc = update_array(ctx, t, &S.mesh_tlas, &ctx->cap_mesh_tlas))) return rc;
+    S.n_mesh_tlas = bmt ? bmt->count : 0;
+    pack_tlas(bst, t);
+    if ((rc = update_array(ctx, t, &S.sphere_tlas, &ctx->cap_sphere_tlas))) return rc;
+    S.n_sphere_tlas = bst ? bst->count : 0;
+    int lv = std::max(heap_levels(S.n_mesh_tlas), heap_levels(S.n_sphere_tlas));
+    if (lv + 1 > 32)
+      return fail(ctx, URT_ERR_SCENE, "object-level BVH deeper than the reference's 32-entry traversal stack (RS:73-74)");
+    ctx->tlas_stack = std::max(2, lv + 1);
+  }
+  if (n_moved > 0) {
+    URT_HIP(ctx, hipMemcpy(ctx->refit.matrices, matrices.data(), matrices.size() * sizeof(float), hipMemcpyHostToDevice));
+    URT_HIP(ctx, hipMemcpy(ctx->refit.moved, moved.data(), moved.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    URT_HIP(ctx, refit_moved(const_cast<float4*>(S.blas_nodes), ctx->n_blas_nodes, const_cast<float4*>(S.tri_verts), ctx->n_scene_tris,
+                             ctx->refit.vertices, ctx->refit.indices, ctx->refit.depth, std::max(0, ctx->scene_max_depth - 1), ctx->refit.node_mesh,
+                             ctx->refit.matrices, ctx->refit.moved, ctx->refit.ext, n_meshes, ctx->refit.cbox, ctx->stream));
+    ctx->refitted_meshes += (uint64_t)n_moved;
+  }
+  ctx->prev_mesh_objects.assign(bm ? bm->host.begin() : ctx->prev_mesh_objects.begin(), bm ? bm->host.begin() + (ptrdiff_t)((size_t)n_meshes * URT_STRIDE_MESHOBJECT) : ctx->prev_mesh_objects.begin());
+  ctx->scene_dirty = false; ctx->dirty_slots = 0; ctx->dirty_full = false;
+  ctx->scene_epoch++;
+  ctx->incremental_preps++;
+  ctx->last_prepare_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  return URT_OK;
+}
+
 // Derive the device scene from the bound ComputeBuffers (runs at the first dispatch after a change;
 // the reference pays the equivalent in RebuildTrees -> SetData, RM:725-746).
 int prepare_scene(urt_context* ctx) {
+  {
+    int rc = prepare_incremental(ctx);
+    if (rc != 1) return rc;                                 // updated in place (or failed)
+  }
   free_scene(ctx);
   DevScene& S = ctx->ds;
   const Buffer* bm = bound_buffer(ctx, B_MESHOBJECTS);
@@ -412,8 +538,9 @@ int prepare_scene(urt_context* ctx) {
       LbvhOutput o;
       std::string err;
       rc = lbvh_build(in, ctx->stream, o, err);
-      (void)hipFree(raw);
-      if (rc) return fail(ctx, rc, err);
+      if (rc) { (void)hipFree(raw); return fail(ctx, rc, err); }
+      ctx->scene_allocs.push_back(raw);                     // _Vertices / _Indices stay resident: a moved MeshObject is refitted from them
+      ctx->refit.vertices = in.vertices; ctx->refit.indices = in.indices;
       for (void* a : o.allocs) ctx->scene_allocs.push_back(a);
       S.mesh_root = o.mesh_root; S.blas_nodes = o.nodes; S.tri_verts = o.tri_verts; S.tri_norms = o.tri_norms;
       mesh_root_host = o.h_mesh_root; blas_max_depth = o.max_depth; n_blas_nodes = (size_t)o.n_nodes; n_tris = (size_t)o.n_tris;
@@ -460,9 +587,10 @@ int prepare_scene(urt_context* ctx) {
   }
   {
     const float4* p;
-    if ((rc = upload(ctx, mats, &p))) return rc; S.materials = p;
+    if ((rc = upload(ctx, mats, &p))) return rc; S.materials = p; ctx->cap_materials = mats.size() / 4;
   }
   S.n_spheres = n_spheres;
+  ctx->cap_sphere_pr = (size_t)n_spheres;
   // object-level BVHs
   std::vector<float> t;
   const float4* p;
@@ -475,9 +603,9 @@ int prepare_scene(urt_context* ctx) {
       t.insert(t.end(), walk.begin(), walk.end());
     }
   }
-  if ((rc = upload(ctx, t, &p))) return rc; S.mesh_tlas = p; S.n_mesh_tlas = bmt ? bmt->count : 0;
+  if ((rc = upload(ctx, t, &p))) return rc; S.mesh_tlas = p; S.n_mesh_tlas = bmt ? bmt->count : 0; ctx->cap_mesh_tlas = t.size() / 4;
   pack_tlas(bst, t);
-  if ((rc = upload(ctx, t, &p))) return rc; S.sphere_tlas = p; S.n_sphere_tlas = bst ? bst->count : 0;
+  if ((rc = upload(ctx, t, &p))) return rc; S.sphere_tlas = p; S.n_sphere_tlas = bst ? bst->count : 0; ctx->cap_sphere_tlas = t.size() / 4;
 
   // traversal stack budgets (per lane, LDS)
   int lv = std::max(heap_levels(S.n_mesh_tlas), heap_levels(S.n_sphere_tlas));
@@ -494,7 +622,38 @@ int prepare_scene(urt_context* ctx) {
   ctx->watchdog_steps = (unsigned int)std::min<size_t>(0x7fffffffu, 8 * (n_blas_nodes + n_tris) + 4096);
   if ((size_t)(ctx->tlas_stack + ctx->blas_stack) * 64 * 4 * sizeof(int) > 150 * 1024)   // 4-wave workgroup; a CU has 160 KiB
     return fail(ctx, URT_ERR_SCENE, "traversal stacks exceed the LDS of a compute unit");
-  ctx->scene_dirty = false;
+  // what a later in-place update needs (prepare_incremental): the records this scene was prepared from, and — when it has triangle
+  // BVHs — device copies of _Vertices / _Indices plus every node's parent and MeshObject (csrc/refit.hip)
+  ctx->prev_mesh_objects.assign(bm ? bm->host.begin() : ctx->prev_mesh_objects.end(), bm ? bm->host.begin() + (ptrdiff_t)((size_t)n_meshes * URT_STRIDE_MESHOBJECT) : ctx->prev_mesh_objects.end());
+  if (!bm) ctx->prev_mesh_objects.clear();
+  ctx->h_mesh_root = mesh_root_host; ctx->h_small_first = small_first;
+  if (ctx->opt_refit && n_meshes > 0 && n_tris > 0 && bv && bi) {
+    urt_context::RefitAux& R = ctx->refit;
+    auto dev_alloc = [&](void** ptr, size_t bytes) -> int {
+      URT_HIP(ctx, hipMalloc(ptr, std::max<size_t>(bytes, 16)));
+      ctx->scene_allocs.push_back(*ptr);
+      return URT_OK;
+    };
+    if (!R.vertices) {                                        // (the GPU builder has left its copies in place)
+      void *dv = nullptr, *di = nullptr;
+      if ((rc = dev_alloc(&dv, (size_t)bv->count * 12))) return rc;
+      if ((rc = dev_alloc(&di, (size_t)bi->count * 4))) return rc;
+      URT_HIP(ctx, hipMemcpy(dv, bv->host.data(), (size_t)bv->count * 12, hipMemcpyHostToDevice));
+      URT_HIP(ctx, hipMemcpy(di, bi->host.data(), (size_t)bi->count * 4, hipMemcpyHostToDevice));
+      R.vertices = (const float*)dv; R.indices = (const int32_t*)di;
+    }
+    size_t nn = std::max<size_t>(1, n_blas_nodes);
+    if ((rc = dev_alloc((void**)&R.parent, nn * 4))) return rc;
+    if ((rc = dev_alloc((void**)&R.node_mesh, nn * 4))) return rc;
+    if ((rc = dev_alloc((void**)&R.cbox, nn * 64))) return rc;
+    if ((rc = dev_alloc((void**)&R.depth, nn * 4))) return rc;
+    if ((rc = dev_alloc((void**)&R.ext, (size_t)n_meshes * 4))) return rc;
+    if ((rc = dev_alloc((void**)&R.matrices, (size_t)n_meshes * 64))) return rc;
+    if ((rc = dev_alloc((void**)&R.moved, (size_t)n_meshes * 4))) return rc;
+    URT_HIP(ctx, refit_prepare(S.blas_nodes, (int)n_blas_nodes, S.tri_verts, R.parent, R.node_mesh, R.depth, ctx->stream));
+    R.ready = true;
+  }
+  ctx->scene_dirty = false; ctx->dirty_slots = 0; ctx->dirty_full = false;
   ctx->scene_epoch++;
   ctx->last_prepare_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
   return URT_OK;
@@ -1078,9 +1237,13 @@ int urt_buffer_set_data(urt_context* ctx, urt_handle buffer, const void* data, i
   Buffer& b = it->second;
   if (count < 0 || count > b.count) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "SetData: more elements than the buffer holds");
   if (count > 0 && !data) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "SetData: data is NULL");
-  if (count > 0) std::memcpy(b.host.data(), data, (size_t)count * (size_t)b.stride);
+  // The reference re-uploads EVERY list whenever anything changed (RM:738-745): data equal to what the buffer already holds changes
+  // nothing and dirties nothing (a compare costs what the copy would)
+  const size_t bytes = (size_t)count * (size_t)b.stride;
+  if (b.has_data && (bytes == 0 || std::memcmp(b.host.data(), data, bytes) == 0)) return URT_OK;
+  if (count > 0) std::memcpy(b.host.data(), data, bytes);
   b.has_data = true;
-  for (int s = 0; s < B_COUNT; s++) if (ctx->bound[s] == buffer) ctx->scene_dirty = true;
+  for (int s = 0; s < B_COUNT; s++) if (ctx->bound[s] == buffer) { ctx->scene_dirty = true; ctx->dirty_slots |= 1u << s; }
   return URT_OK;
 }
 
@@ -1097,7 +1260,7 @@ int urt_buffer_release(urt_context* ctx, urt_handle buffer) {
   if (!ctx) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "ctx is NULL");
   auto it = ctx->buffers.find(buffer);
   if (it == ctx->buffers.end()) return fail(ctx, URT_ERR_INVALID_HANDLE, "Release: unknown buffer handle");
-  for (int s = 0; s < B_COUNT; s++) if (ctx->bound[s] == buffer) { ctx->bound[s] = 0; ctx->scene_dirty = true; }
+  for (int s = 0; s < B_COUNT; s++) if (ctx->bound[s] == buffer) { ctx->bound[s] = 0; ctx->scene_dirty = true; ctx->dirty_full = true; }
   ctx->buffers.erase(it);
   return URT_OK;
 }
@@ -1205,7 +1368,7 @@ int urt_shader_set_buffer(urt_context* ctx, int kernel, const char* name, urt_ha
         return fail(ctx, URT_ERR_LAYOUT, std::string("SetBuffer(") + name + "): stride " + std::to_string(it->second.stride) +
                                              " != " + std::to_string(kBindStride[s]) + " (RM:738-745)");
     }
-    if (ctx->bound[s] != buffer) { ctx->bound[s] = buffer; ctx->scene_dirty = true; }   // re-binding the same buffer every frame (RM:787-794) is free
+    if (ctx->bound[s] != buffer) { ctx->bound[s] = buffer; ctx->scene_dirty = true; ctx->dirty_full = true; }   // re-binding the same buffer every frame (RM:787-794) is free
     return URT_OK;
   }
   return fail(ctx, URT_ERR_INVALID_ARGUMENT, std::string("SetBuffer: kernel CSMain has no buffer named ") + name);
@@ -1377,7 +1540,7 @@ int urt_set_option(urt_context* ctx, const char* name, int value) {
   { (void)hipSetDevice(ctx->device); int rc = flush_pending(ctx); if (rc) return rc; }   // deferred frames run with the options they were dispatched under
   if (std::strcmp(name, "blas_builder") == 0) {
     if (value < 0 || value > 1) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "blas_builder must be 0 (host SAH) or 1 (GPU LBVH)");
-    if (value != ctx->opt_blas_builder) ctx->scene_dirty = true;
+    if (value != ctx->opt_blas_builder) { ctx->scene_dirty = true; ctx->dirty_full = true; }
     ctx->opt_blas_builder = value;
   } else if (std::strcmp(name, "frames_per_launch") == 0) {
     if (value < 0 || value > kMaxFramesPerLaunch) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "frames_per_launch must be in [0, 64] (0 = auto)");
@@ -1393,7 +1556,7 @@ int urt_set_option(urt_context* ctx, const char* name, int value) {
   } else if (std::strcmp(name, "blas_leaf_max") == 0) {
     if (value < 1 || value > 8) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "blas_leaf_max must be in [1, 8]");
     set_blas_leaf_max(value);
-    ctx->scene_dirty = true;
+    ctx->scene_dirty = true; ctx->dirty_full = true;
   } else if (std::strcmp(name, "blas_min") == 0) {
     if (value < 0 || value > 256) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "blas_min must be in [0, 256] (0 = auto; kernel_mode 5 counts the waiting rays of a workgroup)");
     ctx->opt_blas_min = value;
@@ -1462,6 +1625,9 @@ int urt_set_option(urt_context* ctx, const char* name, int value) {
   } else if (std::strcmp(name, "work_shards") == 0) {
     if (value < 1 || value > (int)kWorkShards || (value & (value - 1))) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "work_shards must be a power of two in [1, 64]");
     ctx->opt_work_shards = value;
+  } else if (std::strcmp(name, "refit") == 0) {
+    ctx->opt_refit = value ? 1 : 0;
+    ctx->scene_dirty = true; ctx->dirty_full = true;
   } else if (std::strcmp(name, "watchdog_cap") == 0) {
     if (value < 0) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "watchdog_cap must be >= 0 (0 = auto)");
     ctx->opt_watchdog_cap = value;
@@ -1555,6 +1721,13 @@ int urt_debug_blas_cache_stats(urt_context* ctx, uint64_t* out_reused, uint64_t*
   std::lock_guard<std::mutex> g(ctx->blas_cache.lock);
   if (out_reused) *out_reused = ctx->blas_cache.hits;
   if (out_built) *out_built = ctx->blas_cache.builds;
+  return URT_OK;
+}
+
+int urt_debug_refit_stats(urt_context* ctx, uint64_t* out_refitted_meshes, uint64_t* out_incremental_preparations) {
+  if (!ctx) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  if (out_refitted_meshes) *out_refitted_meshes = ctx->refitted_meshes;
+  if (out_incremental_preparations) *out_incremental_preparations = ctx->incremental_preps;
   return URT_OK;
 }
 

@@ -1335,11 +1335,18 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
         // majority vote: this trip runs EITHER the interior-node step OR the leaf step, for the lanes that hold that kind
         // of cursor (the others wait one trip) — so a trip costs one of the two bodies, not their sum.
         int nI = __popcll(wballot(c >= 0));
-        if (2 * nI >= nA) {
+#ifndef URT_VOTE_NUM                       // A/B builds: node trip iff nI * URT_VOTE_DEN >= nA * URT_VOTE_NUM (default 1/2: the majority)
+#define URT_VOTE_NUM 1
+#define URT_VOTE_DEN 2
+#endif
+        if (URT_VOTE_DEN * nI >= URT_VOTE_NUM * nA) {
           if (c >= 0) {
             if (COUNT) lc.blas_nodes++;
             const float4* n = (const float4*)((const char*)S.blas_nodes + ((uint32_t)c << 6));
             float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
+#ifdef URT_EXTRA_NODE_LOADS                // A/B probe: how sensitive is the loop to vector-memory instructions per node step?
+            { const float4* n2 = (const float4*)((const char*)S.blas_nodes + ((uint32_t)(c > 0 ? c - 1 : c + 1) << 6)); float4 x0 = n2[0], x1 = n2[1]; asm volatile("" :: "v"(x0.x), "v"(x1.x)); }
+#endif
             c = blas_node_eval_flat(q0, q1, q2, q3, R, best.t, bl, sp);
           }
         } else if (c < 0 && c != kBlasDone) {

@@ -536,3 +536,121 @@ def many_meshes_scene(width=128, height=80, n=300, level=0, sky=None) -> Scene:
 
 
 CONFIGS = {"C1": config1, "C2": config2, "C3": config3, "C4": config4, "C5": config5, "C3D": config3_dense}
+
+
+# --- the reference's own scenes (tests/golden/scene_*.json, mined from Assets/Scenes/*.unity by tests/golden/make_scene_fixtures.py) ---
+def trs_quat(translate=(0, 0, 0), quat=(0, 0, 0, 1), scale=(1, 1, 1)) -> np.ndarray:
+    """Matrix4x4.TRS(position, rotation, scale) as 16 floats in Unity memory order (column-major); quat = (x, y, z, w)."""
+    x, y, z, w = (float(c) for c in quat)
+    r = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                  [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]], dtype=np.float64)
+    m = np.eye(4, dtype=np.float64)
+    m[:3, :3] = r @ np.diag(np.array(scale, dtype=np.float64))
+    m[:3, 3] = translate
+    return np.ascontiguousarray(m.T.astype(np.float32).reshape(16))
+
+
+def unity_builtin_mesh(kind: str):
+    """Stand-ins for Unity's built-in meshes (the editor's default resources are not in the reference's tree): same shape, extent
+    and triangle count as the originals — cube 12, quad 2, plane 200, cylinder 80 (20 sides, radius 0.5, height 2), capsule 832
+    (radius 0.5, height 2), sphere 768 — with one vertex per position (the reference welds normals by position anyway, RM:351)
+    and triangles ordered so that rays from outside pass the back-face culling of RS:211.  Vertex order inside the originals is
+    unknown; nothing in the path depends on it except the order of exact ties."""
+    if kind == "cube":
+        v = np.array([[x, y, z] for x in (-0.5, 0.5) for y in (-0.5, 0.5) for z in (-0.5, 0.5)], dtype=np.float32)
+        faces = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
+        t = np.array([[a, b, c] for a, b, c, d in faces] + [[a, c, d] for a, b, c, d in faces], dtype=np.int32)
+        return v, _orient_outward(v, t)
+    if kind == "quad":                                     # unit quad in the xy plane, visible from -z
+        v, t = quad((-0.5, -0.5, 0), (0.5, -0.5, 0), (0.5, 0.5, 0), (-0.5, 0.5, 0))
+        if not front_facing(v[0].astype(np.float64), v[1].astype(np.float64), v[2].astype(np.float64), np.array([0.0, 0.0, 1.0])):
+            t = t[:, [0, 2, 1]]
+        return v, t
+    if kind == "plane":                                    # 10 x 10 units, 10 x 10 cells, visible from +y
+        n = 11
+        v = np.array([[-5 + i, 0, -5 + j] for j in range(n) for i in range(n)], dtype=np.float32)
+        t = []
+        for j in range(n - 1):
+            for i in range(n - 1):
+                a, b, c, d = j * n + i, j * n + i + 1, (j + 1) * n + i + 1, (j + 1) * n + i
+                t += [[a, b, c], [a, c, d]]
+        t = np.array(t, dtype=np.int32)
+        if not front_facing(v[t[0, 0]].astype(np.float64), v[t[0, 1]].astype(np.float64), v[t[0, 2]].astype(np.float64), np.array([0.0, -1.0, 0.0])):
+            t = t[:, [0, 2, 1]]
+        return v, t
+    if kind in ("cylinder", "capsule", "sphere"):
+        sides = {"cylinder": 20, "capsule": 26, "sphere": 24}[kind]
+        rings = []                                         # (y, radius) from the bottom pole to the top pole, poles excluded
+        if kind == "cylinder":
+            rings = [(-1.0, 0.5), (1.0, 0.5)]
+        elif kind == "capsule":                            # two hemispheres of radius 0.5 around y = -0.5 / +0.5: 7 quad rows + a fan each, one row between
+            for k in range(1, 9):
+                a = math.pi / 2 * k / 8
+                rings.append((-0.5 - 0.5 * math.cos(a), 0.5 * math.sin(a)))
+            for k in range(8, 0, -1):
+                a = math.pi / 2 * k / 8
+                rings.append((0.5 + 0.5 * math.cos(a), 0.5 * math.sin(a)))
+        else:                                              # 17 latitudes: 15 quad rows + two fans = 2 * 24 * 16 = 768 triangles
+            for k in range(1, 17):
+                a = math.pi * k / 17
+                rings.append((-0.5 * math.cos(a), 0.5 * math.sin(a)))
+        ybot, ytop = (-1.0, 1.0) if kind != "sphere" else (-0.5, 0.5)
+        verts = [[0.0, ybot, 0.0]]
+        for y, r in rings:
+            for s_ in range(sides):
+                a = 2 * math.pi * s_ / sides
+                verts.append([r * math.cos(a), y, r * math.sin(a)])
+        verts.append([0.0, ytop, 0.0])
+        top = len(verts) - 1
+        t = []
+        for s_ in range(sides):
+            t.append([0, 1 + s_, 1 + (s_ + 1) % sides])
+            base = 1 + (len(rings) - 1) * sides
+            t.append([top, base + (s_ + 1) % sides, base + s_])
+        for q in range(len(rings) - 1):
+            for s_ in range(sides):
+                a, b = 1 + q * sides + s_, 1 + q * sides + (s_ + 1) % sides
+                c, d = a + sides, b + sides
+                t += [[a, c, d], [a, d, b]]
+        verts = np.array(verts, dtype=np.float32)
+        return verts, _orient_outward(verts, np.array(t, dtype=np.int32))
+    raise ValueError(f"no stand-in for Unity mesh {kind!r}")
+
+
+def from_unity_fixture(fixture, width: int, height: int, sky=None) -> Scene:
+    """A scene of the reference itself, from its mined fixture (a dict or a path to tests/golden/scene_*.json): the ENABLED
+    RayTraceObjects in the order the fixture lists them, the scene's camera (position, pitch/yaw from its quaternion, field of view)
+    and its numBounces / numRays.  Flattened like RebuildObjectLists (RM:262-336): spheres from the collider radius x largest
+    lossy scale (RO:33), meshes concatenated with their localToWorldMatrix."""
+    import json
+    if not isinstance(fixture, dict):
+        fixture = json.load(open(fixture))
+    b = MeshSceneBuilder()
+    sph = []
+    for o in fixture["objects"]:
+        if not o["enabled"]:
+            continue
+        lighting = _params(tuple(o["albedoColor"]), tuple(o["specularColor"]), tuple(o["emissionColor"]), float(o["smoothness"]))
+        if o["type"] == "sphere":
+            s_ = np.zeros((), dtype=SPHERE_DT)
+            s_["position"], s_["radius"], s_["lighting"] = tuple(o["position"]), float(o["radius"]), lighting
+            sph.append(s_)
+        else:
+            v, t = unity_builtin_mesh(o["mesh"])
+            b.add(v, t, trs_quat(o["position"], o["rotation"], o["scale"]), lighting)
+    mo, vv, ii, nn, bvh = b.finish()
+    spheres = np.array(sph, dtype=SPHERE_DT) if sph else np.zeros(0, SPHERE_DT)
+    cam = fixture["camera"]
+    x, y, z, w = cam["rotation"]
+    fwd = (2 * (x * z + y * w), 2 * (y * z - x * w), 1 - 2 * (x * x + y * y))           # rotation applied to (0, 0, 1)
+    yaw, pitch = math.degrees(math.atan2(fwd[0], fwd[2])), -math.degrees(math.asin(max(-1.0, min(1.0, fwd[1]))))
+    sc = Scene(f"unity-{fixture['source'].split('.')[0]}", width, height, int(fixture["numBounces"]), int(fixture["numRays"]), mesh_objects=mo, vertices=vv,
+               indices=ii, normals=nn, mesh_bvh=bvh if len(mo) else np.zeros(0, BVHNODE_DT), spheres=spheres,
+               sphere_bvh=build_object_bvh(*sphere_bounds(spheres)) if len(spheres) else np.zeros(0, BVHNODE_DT),
+               sky=sky if sky is not None else make_sky(512, 256))
+    name = sc.name
+    sc = sc.resized(width, height, position=tuple(cam["position"]), fov_deg=float(cam["field_of_view"]), near=float(cam["near"]), far=float(cam["far"]),
+                    yaw_deg=yaw, pitch_deg=pitch)
+    sc.name = name
+    return sc

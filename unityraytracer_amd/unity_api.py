@@ -74,6 +74,12 @@ class Context:
     def reset_counters(self):
         self.check(self.lib.urt_reset_counters(self._h))
 
+    def refit_stats(self) -> tuple:
+        """(MeshObjects refitted on the GPU, scene preparations done in place) since the context was created."""
+        a, b = C.c_uint64(), C.c_uint64()
+        self.check(self.lib.urt_debug_refit_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def serve_stats(self) -> dict:
         """kernel_mode 5 with count_stats: the shared traversal service since the last reset_counters()."""
         a = (C.c_ulonglong * 6)()
