@@ -192,6 +192,10 @@ typedef struct urt_counters {
  *                  "pool_other_min" (1..64),
  *          "blas_leaf_max" (1..8: triangles per BVH leaf; rebuilds the BVH),
  *          "stack_pad" (0..96: test hook, unused extra entries per traversal stack -> the > 64 KiB LDS launch path),
+ *          "qnodes" (0 off, the default | 1 on | -1 on unless some MeshObject spans fewer than 1024 grid cells: the traversal loop of the default
+ *                    kernel reads 32-byte quantized copies of the triangle-BVH nodes — two vector loads per node step instead of four; conservative
+ *                    boxes on one 16-bit grid over the whole forest, csrc/qnodes.hip.  A measured alternative: same pixels, -1.3 % frame time on
+ *                    single-mesh scenes, +1.3 % on C4 / C5: the loop waits on the latency of one dependent fetch per step, not on its width),
  *          "refit" (0/1, default 1: moved MeshObjects are refitted on the GPU instead of rebuilt — see urt_debug_refit_stats),
  *          "watchdog_cap" (test hook: scheduler trips a wave may make before it gives up; 0 = auto = 2^24 x frames of the launch x
  *                          max(1, numRays x numBounces / 8))

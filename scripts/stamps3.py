@@ -41,6 +41,10 @@ for (w, h, b), wpc in itertools.product(((1920, 1080, 8),), (20,)):
         print(f"   {names[q]:5s}: {t[:, q].sum() / life.sum() * 100:5.1f} % of wave time, {trips[:, q].mean():7.1f} trips/wave, {lanes[:, q].sum() / max(1, trips[:, q].sum()):5.1f} lanes/trip, {t[:, q].sum() / max(1, trips[:, q].sum()):7.2f} us/trip")
     print(f"   BLAS inner: {trips[:, 3].mean():8.1f} steps/wave, {lanes[:, 3].sum() / max(1, trips[:, 3].sum()):5.1f} active lanes/step, {t[:, 1].sum() / max(1, trips[:, 3].sum()) * 1000:7.1f} ns/step")
     fs = st[:, 25:32].astype(np.float64)
+    if fs[:, 3].sum() == 0 and fs[:, 2].sum() > 0:               # single-mesh instantiation: slots 25-27 hold the refill's split
+        print(f"   REFILL: {fs[:, 2].mean():7.1f} refills/wave; work-counter hand-out {fs[:, 0].sum() / 100 / life.sum() * 100:5.1f} % of wave time ({fs[:, 0].sum() / 100 / fs[:, 2].sum():5.2f} us each), "
+              f"camera rays {fs[:, 1].sum() / 100 / life.sum() * 100:5.1f} % ({fs[:, 1].sum() / 100 / fs[:, 2].sum():5.2f} us each); "
+              f"unaccounted {(1 - (t[:, 0:3].sum() + (fs[:, 0].sum() + fs[:, 1].sum()) / 100) / life.sum()) * 100:5.1f} %")
     if fs[:, 3].sum() > 0:                                       # listed FRONT: where its time goes
         ft = t[:, 0].sum()
         print(f"   FRONT split: heap walk {fs[:, 0].sum() / 100 / ft * 100:5.1f} % ({fs[:, 0].sum() / 100 / fs[:, 3].sum():6.2f} us per walk, {fs[:, 6].sum() / fs[:, 3].sum():5.1f} fresh lanes), "

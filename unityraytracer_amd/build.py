@@ -17,7 +17,7 @@ HIPCC_FLAGS = [
     "-Xarch_host", "-march=x86-64-v3",   # inline hardware fma for the host-side vertex pre-transform
     "-Wall", "-Wno-unused-function",
 ]
-SOURCES = ["kernels.hip", "lbvh.hip", "refit.hip", "context.cpp", "blas_builder.cpp", "host_scene.cpp", "host_io.cpp", "host_debug.cpp", "group.cpp"]
+SOURCES = ["kernels.hip", "lbvh.hip", "refit.hip", "qnodes.hip", "context.cpp", "blas_builder.cpp", "host_scene.cpp", "host_io.cpp", "host_debug.cpp", "group.cpp"]
 
 
 def _newer(target: str, deps) -> bool:

@@ -24,6 +24,7 @@
 #include "kernels.h"
 #include "lbvh.h"
 #include "refit.h"
+#include "qnodes.h"
 #include "urt_device.h"
 
 #include <chrono>
@@ -89,6 +90,9 @@ struct urt_context {
   unsigned int dirty_slots = 0;
   bool dirty_full = true;
   int opt_refit = 1;                        // 0 = always prepare from scratch
+  int opt_qnodes = 0;                       // 32-byte quantized nodes in the traversal loop: 0 = off (default: measured -1.3 % on C3 / C3D, +1.3 % on C4 / C5 — the loop waits on the latency of ONE dependent fetch per step, not on its width), 1 = on, -1 = on unless a MeshObject is only a few grid cells wide
+  float4* qbuf = nullptr;                   // frame + quantized nodes of the prepared scene (in scene_allocs)
+  float qnode_quality = 0;                  // smallest MeshObject extent in grid cells (csrc/qnodes.hip)
   std::vector<uint8_t> prev_mesh_objects;   // the _MeshObjects records of the prepared scene
   std::vector<int32_t> h_mesh_root, h_small_first;
   struct RefitAux {                         // device-resident, part of the prepared scene (scene_allocs)
@@ -229,6 +233,7 @@ void free_scene(urt_context* ctx) {
   ctx->scene_allocs.clear();
   ctx->ds = DevScene{};
   ctx->refit = urt_context::RefitAux{};
+  ctx->qbuf = nullptr;
   ctx->cap_materials = ctx->cap_mesh_tlas = ctx->cap_sphere_tlas = ctx->cap_sphere_pr = 0;
 }
 
@@ -369,6 +374,22 @@ void pack_tlas(const Buffer* b, std::vector<float>& out) {
   }
 }
 
+// (Re)derive the quantized nodes from the float nodes of the prepared scene and decide whether the traversal loop uses them.
+int requantize(urt_context* ctx) {
+  DevScene& S = ctx->ds;
+  S.blas_qnodes = nullptr;
+  if (ctx->opt_qnodes == 0 || !ctx->qbuf || ctx->n_blas_nodes <= 0) return URT_OK;
+  URT_HIP(ctx, quantize_nodes(S.blas_nodes, ctx->n_blas_nodes, S.mesh_root, S.n_meshes, ctx->qbuf, ctx->stream));
+  float4 f0;
+  URT_HIP(ctx, hipMemcpyAsync(&f0, ctx->qbuf, sizeof f0, hipMemcpyDeviceToHost, ctx->stream));
+  URT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->qnode_quality = f0.w;
+  // one grid for the whole forest: a MeshObject that spans only a few hundred cells would have boxes of a few cells — every ray through
+  // it would walk most of its tree.  Such scenes keep the float nodes (auto); "qnodes" = 1 insists.
+  if (ctx->opt_qnodes == 1 || f0.w >= 1024.0f) S.blas_qnodes = ctx->qbuf;
+  return URT_OK;
+}
+
 // Update a small device array of the prepared scene: in place while it fits its allocation, else a new allocation (the old one
 // stays in scene_allocs until the next full preparation).  The stream has been waited for.
 int update_array(urt_context* ctx, const std::vector<float>& v, const float4** dev, size_t* cap_f4) {
@@ -462,6 +483,7 @@ int prepare_incremental(urt_context* ctx) {
                              ctx->refit.vertices, ctx->refit.indices, ctx->refit.depth, std::max(0, ctx->scene_max_depth - 1), ctx->refit.node_mesh,
                              ctx->refit.matrices, ctx->refit.moved, ctx->refit.ext, n_meshes, ctx->refit.cbox, ctx->stream));
     ctx->refitted_meshes += (uint64_t)n_moved;
+    if ((rc = requantize(ctx))) return rc;
   }
   ctx->prev_mesh_objects.assign(bm ? bm->host.begin() : ctx->prev_mesh_objects.begin(), bm ? bm->host.begin() + (ptrdiff_t)((size_t)n_meshes * URT_STRIDE_MESHOBJECT) : ctx->prev_mesh_objects.begin());
   ctx->scene_dirty = false; ctx->dirty_slots = 0; ctx->dirty_full = false;
@@ -622,6 +644,13 @@ int prepare_scene(urt_context* ctx) {
   ctx->watchdog_steps = (unsigned int)std::min<size_t>(0x7fffffffu, 8 * (n_blas_nodes + n_tris) + 4096);
   if ((size_t)(ctx->tlas_stack + ctx->blas_stack) * 64 * 4 * sizeof(int) > 150 * 1024)   // 4-wave workgroup; a CU has 160 KiB
     return fail(ctx, URT_ERR_SCENE, "traversal stacks exceed the LDS of a compute unit");
+  if (ctx->opt_qnodes != 0 && n_blas_nodes > 0) {             // 32-byte quantized nodes for the traversal loop (csrc/qnodes.hip)
+    void* q = nullptr;
+    URT_HIP(ctx, hipMalloc(&q, (2 + 2 * n_blas_nodes) * sizeof(float4)));
+    ctx->scene_allocs.push_back(q);
+    ctx->qbuf = (float4*)q;
+    if ((rc = requantize(ctx))) return rc;
+  }
   // what a later in-place update needs (prepare_incremental): the records this scene was prepared from, and — when it has triangle
   // BVHs — device copies of _Vertices / _Indices plus every node's parent and MeshObject (csrc/refit.hip)
   ctx->prev_mesh_objects.assign(bm ? bm->host.begin() : ctx->prev_mesh_objects.end(), bm ? bm->host.begin() + (ptrdiff_t)((size_t)n_meshes * URT_STRIDE_MESHOBJECT) : ctx->prev_mesh_objects.end());
@@ -1625,6 +1654,10 @@ int urt_set_option(urt_context* ctx, const char* name, int value) {
   } else if (std::strcmp(name, "work_shards") == 0) {
     if (value < 1 || value > (int)kWorkShards || (value & (value - 1))) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "work_shards must be a power of two in [1, 64]");
     ctx->opt_work_shards = value;
+  } else if (std::strcmp(name, "qnodes") == 0) {
+    if (value < -1 || value > 1) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "qnodes must be -1 (auto), 0 or 1");
+    ctx->opt_qnodes = value;
+    ctx->scene_dirty = true; ctx->dirty_full = true;
   } else if (std::strcmp(name, "refit") == 0) {
     ctx->opt_refit = value ? 1 : 0;
     ctx->scene_dirty = true; ctx->dirty_full = true;

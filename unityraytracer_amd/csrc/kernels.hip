@@ -218,6 +218,47 @@ __device__ __forceinline__ int32_t blas_node_eval_flat(float4 q0, float4 q1, flo
   return nxt;
 }
 
+// The same step on a 32-byte QUANTIZED node (csrc/qnodes.hip): two dwordx4 loads instead of four.  The twelve planes are 16-bit grid
+// coordinates q; a plane's slab value is t = (origin + q cell - (o +- pad)) / d = fma(Q, S, B) with Q = 2^23 + q — built in ONE
+// instruction per plane by putting q into the mantissa of 2^23 (0x4B000000 | q) —, S = cell / d and B = (origin - (o +- pad)) / d - 2^23 S
+// per axis (QRay, derived from the BlasRay at phase entry).  The 2^23 S terms cancel exactly but for the rounding of B: half a cell
+// at worst, covered by the two cells the quantizer adds on every side.  Conservative culling only: the hits are the triangle tests'.
+struct QRay { v3 S, Bp, Bm; };
+__device__ __forceinline__ QRay make_qray(const BlasRay& R, float4 forg, float4 fcell) {
+  QRay Q;
+  Q.S = mk3(fcell.x * R.idir.x, fcell.y * R.idir.y, fcell.z * R.idir.z);
+  Q.Bp = mk3(f_fma(-8388608.0f, Q.S.x, f_fma(forg.x, R.idir.x, R.nop.x)), f_fma(-8388608.0f, Q.S.y, f_fma(forg.y, R.idir.y, R.nop.y)),
+             f_fma(-8388608.0f, Q.S.z, f_fma(forg.z, R.idir.z, R.nop.z)));
+  Q.Bm = mk3(f_fma(-8388608.0f, Q.S.x, f_fma(forg.x, R.idir.x, R.nom.x)), f_fma(-8388608.0f, Q.S.y, f_fma(forg.y, R.idir.y, R.nom.y)),
+             f_fma(-8388608.0f, Q.S.z, f_fma(forg.z, R.idir.z, R.nom.z)));
+  return Q;
+}
+__device__ __forceinline__ float q_lo16(float w) { return as_float((int)(((unsigned int)as_int(w) & 0xffffu) | 0x4B000000u)); }
+__device__ __forceinline__ float q_hi16(float w) { return as_float((int)__builtin_amdgcn_alignbit(0x4B00u, (unsigned int)as_int(w), 16u)); }
+__device__ __forceinline__ int32_t qnode_eval_flat(float4 u0, float4 u1, const QRay& Q, float tbest, int* stk, int& sp) {
+  int below = stk[max(sp - 1, 0) * 64];
+  // child 0: lo (u0.x lo16, u0.x hi16, u0.y lo16) hi (u0.y hi16, u0.z lo16, u0.z hi16); child 1: the same from u0.w, u1.x, u1.y
+  float a1x = f_fma(q_lo16(u0.x), Q.S.x, Q.Bp.x), a2x = f_fma(q_hi16(u0.y), Q.S.x, Q.Bm.x);
+  float a1y = f_fma(q_hi16(u0.x), Q.S.y, Q.Bp.y), a2y = f_fma(q_lo16(u0.z), Q.S.y, Q.Bm.y);
+  float a1z = f_fma(q_lo16(u0.y), Q.S.z, Q.Bp.z), a2z = f_fma(q_hi16(u0.z), Q.S.z, Q.Bm.z);
+  float tn0 = f_max(f_max(f_min(a1x, a2x), f_min(a1y, a2y)), f_max(f_min(a1z, a2z), 0.0f));
+  float tf0 = f_min(f_min(f_max(a1x, a2x), f_max(a1y, a2y)), f_min(f_max(a1z, a2z), tbest));
+  float b1x = f_fma(q_lo16(u0.w), Q.S.x, Q.Bp.x), b2x = f_fma(q_hi16(u1.x), Q.S.x, Q.Bm.x);
+  float b1y = f_fma(q_hi16(u0.w), Q.S.y, Q.Bp.y), b2y = f_fma(q_lo16(u1.y), Q.S.y, Q.Bm.y);
+  float b1z = f_fma(q_lo16(u1.x), Q.S.z, Q.Bp.z), b2z = f_fma(q_hi16(u1.y), Q.S.z, Q.Bm.z);
+  float tn1 = f_max(f_max(f_min(b1x, b2x), f_min(b1y, b2y)), f_max(f_min(b1z, b2z), 0.0f));
+  float tf1 = f_min(f_min(f_max(b1x, b2x), f_max(b1y, b2y)), f_min(f_max(b1z, b2z), tbest));
+  bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
+  int32_t c0 = as_int(u1.z), c1 = as_int(u1.w);
+  bool both = h0 && h1, none = !h0 && !h1;
+  bool first1 = h1 && (!h0 || tn1 < tn0);
+  stk[sp * 64] = first1 ? c0 : c1;
+  int32_t popped = sp > 0 ? below : kBlasDone;
+  int32_t nxt = none ? popped : (first1 ? c1 : c0);
+  sp += both ? 1 : (none && sp > 0 ? -1 : 0);
+  return nxt;
+}
+
 // One interior-node step: slab-test both children against [0, tbest], descend into the nearer hit child (ties: child 0),
 // push the other; returns the next cursor.
 template <bool COUNT>
@@ -1142,7 +1183,9 @@ __device__ __forceinline__ void report_watchdog(const FrameParams& P, DevCounter
 // NEXT frame once the current one is handed out, so only the last frame of a launch pays the drain of the long paths.
 // FMODE: how FRONT treats MeshObjects — 0: a ray that must enter a triangle BVH goes to the BLAS phase at once (one mesh);
 // 1: it first walks the LDS-resident top of that BVH inside FRONT (several meshes); 2: listed form of 1 (front_listed above).
-template <bool COUNT, int BLOCK, int FMODE, bool MULTI>
+// QN: the traversal loop reads the 32-byte quantized nodes (S.blas_qnodes; never together with COUNT: the counting instantiation walks
+// the float nodes, like the oracle).
+template <bool COUNT, int BLOCK, int FMODE, bool MULTI, bool QN = false>
 __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, FrameParams P, const FrameUniforms* __restrict__ T, float4* __restrict__ result, DevCounters* ctr,
                                                unsigned int* __restrict__ next) {
   // LDS of the workgroup: [top of the triangle-BVH forest: top_nodes x 64 B, shared by its waves][stacks of wave 0][wave 1]...
@@ -1225,6 +1268,7 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
   unsigned long long c_begin = __builtin_amdgcn_s_memtime();
   unsigned long long dr_trips[4] = {0, 0, 0, 0}, dr_t[3] = {0, 0, 0}, dr_live = 0, dr_lanes3 = 0;   // after the work ran dry
   unsigned long long fs_arr[7] = {0, 0, 0, 0, 0, 0, 0};   // listed FRONT: time in the heap walk / single-leaf tests / BVH-top walks, walks, single-leaf rounds, top walks, fresh lanes walked
+  unsigned long long rf_t[3] = {0, 0, 0};                  // refill: time in the work-counter hand-out (the atomic's round trip), in the camera rays, refills
 #endif
 
   for (;;) {
@@ -1239,10 +1283,19 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
     int nK = __popcll(wballot(st == ST_SKY));
     int nF = __popcll(wballot(st == ST_FRONT || st == ST_RESUME));
     // ---- refill dead lanes from the frame's work counter (one atomic per refill): when enough lanes are dead, or when
-    // nothing else is left to run ----
+    // nothing else is left to run.  The atomic takes 2.3 us to return (7.6 % of a wave's time on C3, profiles/r03_logs/r3_stamps_refill.log),
+    // but hiding it buys nothing — the SIMDs are busy with the other waves' VALU work meanwhile (4 cycles x VALU instructions = the
+    // launch's SIMD cycles): issuing it a trip early cost +23 % (r3_ab_split_refill.log: lanes stay dead a trip longer), reserving several
+    // tiles per atomic +4 % (r3_ab_refill_chunk.log: more live state in the loop). ----
     if (!exhausted && nD > 0 && (nD >= P.refill_min || nB + nS + nK + nF == 0)) {
       int x = 0, y = 0, frame = 0;
+#ifdef URT_STAMPS
+      unsigned long long t_rf = wall_clock64();
+#endif
       bool got = wave_fetch_pixels(P, mD, st == ST_DEAD, next, ntiles, wc, exhausted, x, y, tiles_per_frame, &frame);
+#ifdef URT_STAMPS
+      rf_t[0] += wall_clock64() - t_rf; t_rf = wall_clock64();
+#endif
       for_each_frame(got, frame, [&](int f, bool mine) {
         if (mine) {
           st = ST_FRONT;
@@ -1251,6 +1304,9 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
           camera_ray_frame(T, f, P, x, y, true, seed, o, d);
         }
       });
+#ifdef URT_STAMPS
+      rf_t[1] += wall_clock64() - t_rf; rf_t[2]++;
+#endif
       nF = __popcll(wballot(st == ST_FRONT || st == ST_RESUME));
       nD = __popcll(wballot(st == ST_DEAD));
     }
@@ -1324,6 +1380,8 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
       int32_t c = mine ? cur : kBlasDone;
       int budget = __builtin_amdgcn_readfirstlane((int)min(P.watchdog_steps, 0x7fffffffu));   // trips left before the watchdog ends this phase (counted down: no kernel argument in the loop)
       const int exit_s = __builtin_amdgcn_readfirstlane(exit_below);
+      QRay Q;
+      if (QN) Q = make_qray(R, S.blas_qnodes[0], S.blas_qnodes[1]);     // the grid frame: two wave-uniform loads per phase entry
       for (;;) {
         int nA = __popcll(wballot(c != kBlasDone));
         if (nA < exit_s) break;
@@ -1340,7 +1398,13 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
 #define URT_VOTE_DEN 2
 #endif
         if (URT_VOTE_DEN * nI >= URT_VOTE_NUM * nA) {
-          if (c >= 0) {
+          if (QN) {
+            if (c >= 0) {
+              const float4* n = (const float4*)((const char*)(S.blas_qnodes + 2) + ((uint32_t)c << 5));
+              float4 u0 = n[0], u1 = n[1];
+              c = qnode_eval_flat(u0, u1, Q, best.t, bl, sp);
+            }
+          } else if (c >= 0) {
             if (COUNT) lc.blas_nodes++;
             const float4* n = (const float4*)((const char*)S.blas_nodes + ((uint32_t)c << 6));
             float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
@@ -1406,6 +1470,7 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
     for (int q = 0; q < 4; q++) { sp_[w + q] = ph_t[q]; sp_[w + 4 + q] = ph_lanes[q]; sp_[w + 8 + q] = ph_trips[q]; }
     sp_[w + 12] = t_begin; sp_[w + 13] = wall_clock64(); sp_[w + 14] = t_dry; sp_[w + 15] = __builtin_amdgcn_s_memtime() - c_begin;
     for (int q = 0; q < 7; q++) sp_[w + 25 + q] = fs_arr[q];
+    if (FMODE < 2) { sp_[w + 25] = rf_t[0]; sp_[w + 26] = rf_t[1]; sp_[w + 27] = rf_t[2]; sp_[w + 28] = 0; }     // (single-mesh instantiations: no FRONT split, the refill's instead)
   }
 #endif
   if (watchdog && (threadIdx.x & 63) == 0) report_watchdog(P, ctr);
@@ -2281,15 +2346,22 @@ size_t sched_lds_bytes(const DevScene& S, const FrameParams& P) {
   return f4 * 16 + (size_t)(P.tlas_stack + P.blas_stack) * 64 * (size_t)(P.block_threads / 64) * sizeof(int);
 }
 
+template <bool COUNT, int BLOCK, int FMODE, bool MULTI, bool QN>
+static hipError_t launch_sched_q(const DevScene& S, const FrameParams& P, const FrameUniforms* T, float4* result, DevCounters* ctr,
+                                 unsigned int* next, int n_blocks, size_t lds, hipStream_t st) {
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_sched<COUNT, BLOCK, FMODE, MULTI, QN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL((k_sched<COUNT, BLOCK, FMODE, MULTI, QN>), dim3(n_blocks), dim3(BLOCK), lds, st, S, P, T, result, ctr, next);
+  return hipGetLastError();
+}
+
 template <bool COUNT, int BLOCK, int FMODE, bool MULTI>
 static hipError_t launch_sched_t(const DevScene& S, const FrameParams& P, const FrameUniforms* T, float4* result, DevCounters* ctr,
                                  unsigned int* next, int n_blocks, size_t lds, hipStream_t st) {
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_sched<COUNT, BLOCK, FMODE, MULTI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-  }
-  hipLaunchKernelGGL((k_sched<COUNT, BLOCK, FMODE, MULTI>), dim3(n_blocks), dim3(BLOCK), lds, st, S, P, T, result, ctr, next);
-  return hipGetLastError();
+  if (!COUNT && S.blas_qnodes) return launch_sched_q<false, BLOCK, FMODE, MULTI, true>(S, P, T, result, ctr, next, n_blocks, lds, st);
+  return launch_sched_q<COUNT, BLOCK, FMODE, MULTI, false>(S, P, T, result, ctr, next, n_blocks, lds, st);
 }
 
 template <bool COUNT, int BLOCK, int FMODE>
