@@ -43,6 +43,14 @@ if stats:
             r = max(rows, key=lambda r: int(r["Start_Timestamp"]))
             last_ns = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
             print("timed launch (last of", len(rows), "):", last_ns, "ns")
+            # every launch of the trace kernels in the run, in order (the stats file only has their average): clock warm-up launches,
+            # the W warm-up frames, the timed launch(es), then the counting replay (k_sched<true ...>)
+            allk = sorted((r for r in csv.DictReader(open(tf)) if "k_sched<" in r["Kernel_Name"]), key=lambda r: int(r["Start_Timestamp"]))
+            with open(os.path.join(dst, f"{prefix}_kernel_launches.csv"), "w") as f:
+                f.write("launch,kernel,duration_ns\n")
+                for k, r in enumerate(allk):
+                    name = r["Kernel_Name"].replace("void (anonymous namespace)::", "").split("(")[0]
+                    f.write(f'{k},"{name}",{int(r["End_Timestamp"]) - int(r["Start_Timestamp"])}\n')
 pmc = {}
 for f in newest(os.path.join(src, "pmc_*", "**", "*counter_collection.csv")):
     acc = {}
@@ -76,11 +84,14 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
     if all(k in pmc for k in need):
         cycles = pmc["GRBM_GUI_ACTIVE"] / 8.0                     # per XCD: the launch's active cycles
         entry["issue"] = {
-            "valu_frac": round(pmc["SQ_INSTS_VALU"] / 1024.0 / cycles / 0.5, 4),      # of one wave64 VALU instruction per 2 cycles per SIMD (1024 SIMDs)
+            # one wave64 VALU instruction per 4 cycles per SIMD (16 lanes x 4): the rate non-packed VALU work issues at on this chip — the
+            # launch's SIMD cycles ARE 4 x its VALU instructions (1.01-1.02 on every profile taken): the kernel sits on that ceiling
+            "valu_frac": round(4.0 * pmc["SQ_INSTS_VALU"] / 1024.0 / cycles, 4),
+            "valu_frac_of_2_cycle_rate": round(2.0 * pmc["SQ_INSTS_VALU"] / 1024.0 / cycles, 4),      # against the guide's v_fma_f32 figure (2 cycles with several waves)
             "lane_util": round(pmc["SQ_THREAD_CYCLES_VALU"] / (pmc["SQ_INSTS_VALU"] * 64.0), 4),
             "wait_frac": round(pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"], 4),
             "valu_insts_per_frame": None if not fpl else round(pmc["SQ_INSTS_VALU"] / fpl),
-            "source": f"profiles/{prefix}_pmc_k_sched.json: SQ_INSTS_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE/8 cycles x 0.5), SQ_THREAD_CYCLES_VALU / (SQ_INSTS_VALU x 64), SQ_WAIT_ANY / SQ_WAVE_CYCLES of the last timed launch"}
+            "source": f"profiles/{prefix}_pmc_k_sched.json: 4 x SQ_INSTS_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE/8 cycles), SQ_THREAD_CYCLES_VALU / (SQ_INSTS_VALU x 64), SQ_WAIT_ANY / SQ_WAVE_CYCLES of the last timed launch"}
     c = allcfg["configs"].setdefault(cfg, {})
     if "by_frames_per_launch" not in c:                           # (round-2 layout: one flat entry per config)
         old = dict(c); c.clear(); c["by_frames_per_launch"] = {}

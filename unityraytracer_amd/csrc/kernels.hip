@@ -1382,6 +1382,9 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
       const int exit_s = __builtin_amdgcn_readfirstlane(exit_below);
       QRay Q;
       if (QN) Q = make_qray(R, S.blas_qnodes[0], S.blas_qnodes[1]);     // the grid frame: two wave-uniform loads per phase entry
+#ifdef URT_MINORITY
+      int starve = 0;
+#endif
       for (;;) {
         int nA = __popcll(wballot(c != kBlasDone));
         if (nA < exit_s) break;
@@ -1397,7 +1400,15 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
 #define URT_VOTE_NUM 1
 #define URT_VOTE_DEN 2
 #endif
-        if (URT_VOTE_DEN * nI >= URT_VOTE_NUM * nA) {
+        bool node_trip = URT_VOTE_DEN * nI >= URT_VOTE_NUM * nA;
+#ifdef URT_MINORITY                          // A/B build: when the minority kind has held >= 40 % of the active lanes for two trips, it gets this trip
+        {
+          int nMin = min(nI, nA - nI);
+          starve = 5 * nMin >= 2 * nA ? starve + 1 : 0;
+          if (starve >= 2) { node_trip = !node_trip; starve = 0; }
+        }
+#endif
+        if (node_trip) {
           if (QN) {
             if (c >= 0) {
               const float4* n = (const float4*)((const char*)(S.blas_qnodes + 2) + ((uint32_t)c << 5));
