@@ -84,14 +84,15 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
     if all(k in pmc for k in need):
         cycles = pmc["GRBM_GUI_ACTIVE"] / 8.0                     # per XCD: the launch's active cycles
         entry["issue"] = {
-            # one wave64 VALU instruction per 4 cycles per SIMD (16 lanes x 4): the rate non-packed VALU work issues at on this chip — the
-            # launch's SIMD cycles ARE 4 x its VALU instructions (1.01-1.02 on every profile taken): the kernel sits on that ceiling
-            "valu_frac": round(4.0 * pmc["SQ_INSTS_VALU"] / 1024.0 / cycles, 4),
-            "valu_frac_of_2_cycle_rate": round(2.0 * pmc["SQ_INSTS_VALU"] / 1024.0 / cycles, 4),      # against the guide's v_fma_f32 figure (2 cycles with several waves)
+            # VALU wave-instructions issued, against the chip's best rate: one wave64 fma per 2 cycles per SIMD (1024 SIMDs).  The same chip
+            # issues add/min/max mixes at one per 2.5-2.65 cycles and compare + select pairs at one per 4.1-4.9 (scripts/micro/valu_rate.hip,
+            # profiles/r03_logs/r3_valu_rate_microbench.log): `simd_cycles_per_valu_inst` is what this kernel's mix gets
+            "valu_frac": round(2.0 * pmc["SQ_INSTS_VALU"] / 1024.0 / cycles, 4),
+            "simd_cycles_per_valu_inst": round(1024.0 * cycles / pmc["SQ_INSTS_VALU"], 3),
             "lane_util": round(pmc["SQ_THREAD_CYCLES_VALU"] / (pmc["SQ_INSTS_VALU"] * 64.0), 4),
             "wait_frac": round(pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"], 4),
             "valu_insts_per_frame": None if not fpl else round(pmc["SQ_INSTS_VALU"] / fpl),
-            "source": f"profiles/{prefix}_pmc_k_sched.json: 4 x SQ_INSTS_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE/8 cycles), SQ_THREAD_CYCLES_VALU / (SQ_INSTS_VALU x 64), SQ_WAIT_ANY / SQ_WAVE_CYCLES of the last timed launch"}
+            "source": f"profiles/{prefix}_pmc_k_sched.json: 2 x SQ_INSTS_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE/8 cycles), SQ_THREAD_CYCLES_VALU / (SQ_INSTS_VALU x 64), SQ_WAIT_ANY / SQ_WAVE_CYCLES of the last timed launch"}
     c = allcfg["configs"].setdefault(cfg, {})
     if "by_frames_per_launch" not in c:                           # (round-2 layout: one flat entry per config)
         old = dict(c); c.clear(); c["by_frames_per_launch"] = {}

@@ -1284,8 +1284,7 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
     int nF = __popcll(wballot(st == ST_FRONT || st == ST_RESUME));
     // ---- refill dead lanes from the frame's work counter (one atomic per refill): when enough lanes are dead, or when
     // nothing else is left to run.  The atomic takes 2.3 us to return (7.6 % of a wave's time on C3, profiles/r03_logs/r3_stamps_refill.log),
-    // but hiding it buys nothing — the SIMDs are busy with the other waves' VALU work meanwhile (4 cycles x VALU instructions = the
-    // launch's SIMD cycles): issuing it a trip early cost +23 % (r3_ab_split_refill.log: lanes stay dead a trip longer), reserving several
+    // but hiding it buys nothing — the SIMDs are busy with the other waves' vector work meanwhile: issuing it a trip early cost +23 % (r3_ab_split_refill.log: lanes stay dead a trip longer), reserving several
     // tiles per atomic +4 % (r3_ab_refill_chunk.log: more live state in the loop). ----
     if (!exhausted && nD > 0 && (nD >= P.refill_min || nB + nS + nK + nF == 0)) {
       int x = 0, y = 0, frame = 0;
