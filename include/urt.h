@@ -303,6 +303,11 @@ URT_API int urt_host_log_tree_report(const char* path, int debug_level, int n_me
  * gizmo paints those boxes black).  ray_start3 / ray_end3 may both be NULL.  out_lines = nodes written. */
 URT_API int urt_host_dump_bvh(const char* path, const urt_BVHNode* nodes, int n_nodes, int depth, const float* ray_start3,
                               const float* ray_end3, int* out_lines);
+/* Text stand-in for RayTraceDebug.DrawNormals (RD:165-183): per index slot of every MeshObject the gizmo's base point
+ * MultiplyPoint3x4(_vertices[_indices[i]]) and the tip of its line MultiplyPoint3x4(_vertices[_indices[i]] + _normals[_indices[i]] * 0.1f),
+ * one line "mesh slot (base) -> (tip)".  out_lines = slots written. */
+URT_API int urt_host_dump_normals(const char* path, const void* mesh_objects, int n_meshes, const float* vertices, int n_vertices,
+                                  const int32_t* indices, int n_indices, const float* normals, int n_normals, int* out_lines);
 URT_API const char* urt_host_debug_last_error(void);
 
 /* ---- introspection for tests (host only, no GPU needed) ------------------------------------ */

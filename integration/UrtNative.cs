@@ -106,6 +106,8 @@ internal static class UrtNative {
     [DllImport(Lib)] internal static extern int urt_host_log_scene_counts(string path, int debugLevel, int nSpheres, int nMeshObjects, int nVertices, int nIndices, int nNormals);
     [DllImport(Lib)] internal static extern int urt_host_log_tree_report(string path, int debugLevel, int nMeshObjects, int meshDepth, int meshRealLength, int nSpheres, int sphereDepth, int sphereRealLength);
     [DllImport(Lib)] internal static extern int urt_host_dump_bvh(string path, IntPtr nodes, int nNodes, int depth, float[] rayStart3, float[] rayEnd3, out int lines);
+    [DllImport(Lib)] internal static extern int urt_host_dump_normals(string path, IntPtr meshObjects, int nMeshes, float[] vertices, int nVertices, int[] indices, int nIndices, float[] normals, int nNormals, out int lines);
+    [DllImport(Lib)] internal static extern int urt_debug_refit_stats(IntPtr ctx, out ulong refittedMeshes, out ulong incrementalPreparations);
 
     // Unity's own API returns void and logs on error: the shim keeps that behaviour.
     internal static void Check(IntPtr ctx, int rc) {

@@ -119,8 +119,9 @@ public static class UrtGraphics {
         UrtDevice.Check(UrtDevice.IsGroup ? UrtNative.urt_group_blit_add(UrtDevice.Handle, src.handle, dst.handle, mat.Sample)
                                           : UrtNative.urt_blit_add(UrtDevice.Handle, src.handle, dst.handle, mat.Sample));
     }
-    /// RM:819 "present": on one device a copy; on a group THE frame-end gather — every rank's strips of `src` -> the full image
-    /// `dst` on rank 0.
+    /// RM:819 "present": on one device a copy — queued behind the deferred frames and fused into the blend pass, so presenting every
+    /// frame keeps the 64-frame launches (include/urt.h "Frame batching"); on a group THE frame-end gather — every rank's strips of
+    /// `src` -> the full image `dst` on rank 0.
     public static void Blit(UrtRenderTexture src, UrtRenderTexture dst) {
         UrtDevice.Check(UrtDevice.IsGroup ? UrtNative.urt_group_gather(UrtDevice.Handle, src.handle, dst.handle)
                                           : UrtNative.urt_blit(UrtDevice.Handle, src.handle, dst.handle));

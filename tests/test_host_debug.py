@@ -41,3 +41,25 @@ def test_bvh_dump_walks_the_heap_like_the_gizmo(tmp_path):
     assert d.DrawBVHTree(heap, 2, 1) == 0 and d.last_dump_lines == 3
     d.drawSphereTree = False
     assert d.DrawBVHTree(heap, 4, 1) == 1 and d.DrawBVHTree(heap, 4, 7) == 1
+
+
+def test_draw_normals_text_stand_in(tmp_path):
+    """RayTraceDebug.DrawNormals (RD:165-183): one gizmo per INDEX SLOT of every MeshObject — base point MultiplyPoint3x4(v), tip
+    MultiplyPoint3x4(v + n * 0.1) — as text; 1 when the toggle is off."""
+    import numpy as np
+    sc = scenes.mixed_test_scene(32, 24)
+    d = RayTraceDebug(str(tmp_path), "log", 2)
+    assert d.DrawNormals(sc.mesh_objects, sc.vertices, sc.indices, sc.normals) == 0
+    lines = open(d.last_normals_dump).read().splitlines()
+    assert len(lines) == len(sc.indices) == d.last_normals_lines
+    k = len(lines) // 2
+    mesh, slot = (int(x) for x in lines[k].split()[:2])
+    mo = sc.mesh_objects[mesh]
+    assert mo["indices_offset"] <= slot < mo["indices_offset"] + mo["indices_count"] and slot == k
+    m = np.asarray(mo["localToWorldMatrix"], np.float64).reshape(4, 4).T
+    v = sc.vertices[sc.indices[slot]].astype(np.float64)
+    n = sc.normals[sc.indices[slot]].astype(np.float64)
+    nums = [float(x) for x in lines[k].replace("(", " ").replace(")", " ").replace(",", " ").replace("->", " ").split()[2:]]
+    assert np.allclose(nums[:3], m[:3, :3] @ v + m[:3, 3], atol=1e-5) and np.allclose(nums[3:], m[:3, :3] @ (v + 0.1 * n) + m[:3, 3], atol=1e-5)
+    d.drawNormals = False
+    assert d.DrawNormals(sc.mesh_objects, sc.vertices, sc.indices, sc.normals) == 1

@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "urt_texture_unpack_rows", "urt_texture_unpack_rows_on", "urt_set_option", "urt_get_counters", "urt_reset_counters", "urt_debug_build_blas", "urt_debug_get_blas", "urt_debug_blas_cache_stats",
     "urt_debug_scene_info", "urt_debug_read_scene_blas", "urt_debug_serve_stats", "urt_debug_refit_stats", "urt_host_compute_normals", "urt_host_mesh_leaf_bounds", "urt_host_sphere_leaf_bounds", "urt_host_object_bvh_length",
     "urt_host_build_object_bvh", "urt_host_build_object_bvh_pairing", "urt_host_last_error", "urt_host_load_hdr", "urt_host_write_pfm", "urt_host_write_png",
-    "urt_host_resize_rgba", "urt_host_io_last_error", "urt_host_log", "urt_host_log_scene_counts", "urt_host_log_tree_report", "urt_host_dump_bvh",
+    "urt_host_resize_rgba", "urt_host_io_last_error", "urt_host_log", "urt_host_log_scene_counts", "urt_host_log_tree_report", "urt_host_dump_bvh", "urt_host_dump_normals",
     "urt_host_debug_last_error",
     "urt_group_create", "urt_group_destroy", "urt_group_size", "urt_group_context", "urt_group_last_error", "urt_group_buffer_create",
     "urt_group_buffer_set_data", "urt_group_buffer_release", "urt_group_texture_create", "urt_group_texture_set_pixels",
@@ -104,6 +104,7 @@ def load():
         "urt_debug_scene_info": ([vp, pi, pi, pi, pf], i),
         "urt_debug_serve_stats": ([vp, vp], i),
         "urt_debug_refit_stats": ([vp, vp, vp], i),
+        "urt_host_dump_normals": ([C.c_char_p, vp, i, vp, i, vp, i, vp, i, pi], i),
         "urt_debug_read_scene_blas": ([vp, vp, vp, vp], i),
         "urt_host_compute_normals": ([vp, i, vp, i, vp], i),
         "urt_host_mesh_leaf_bounds": ([vp, i, vp, i, vp, i, i, vp], i),

@@ -106,4 +106,39 @@ int urt_host_dump_bvh(const char* path, const urt_BVHNode* nodes, int n_nodes, i
   return URT_OK;
 }
 
+/* Text stand-in for RayTraceDebug.DrawNormals (RD:165-183): for every index slot of every MeshObject, the base point the gizmo draws its
+ * white sphere at — localToWorldMatrix.MultiplyPoint3x4(_vertices[_indices[i]]) — and the end of its blue line —
+ * MultiplyPoint3x4(_vertices[_indices[i]] + _normals[_indices[i]] * 0.1f).  One line per slot: "mesh slot base -> tip". */
+int urt_host_dump_normals(const char* path, const void* mesh_objects, int n_meshes, const float* vertices, int n_vertices, const int32_t* indices,
+                          int n_indices, const float* normals, int n_normals, int* out_lines) {
+  if (out_lines) *out_lines = 0;
+  if (!path || n_meshes < 0 || (n_meshes > 0 && (!mesh_objects || !vertices || !indices || !normals)))
+    return dbg_fail(URT_ERR_INVALID_ARGUMENT, "urt_host_dump_normals: bad arguments");
+  FILE* f = std::fopen(path, "w");
+  if (!f) return dbg_fail(URT_ERR_INVALID_ARGUMENT, std::string("urt_host_dump_normals: cannot open ") + path);
+  int lines = 0;
+  auto mul_point = [](const float* m, float x, float y, float z, float* o) {      // Matrix4x4.MultiplyPoint3x4: m (column-major) * (x, y, z, 1)
+    for (int r = 0; r < 3; r++) o[r] = m[r] * x + m[4 + r] * y + m[8 + r] * z + m[12 + r];
+  };
+  for (int k = 0; k < n_meshes; k++) {
+    urt_MeshObject mo;
+    std::memcpy(&mo, (const char*)mesh_objects + (size_t)k * sizeof(urt_MeshObject), sizeof mo);
+    for (long i = mo.indices_offset; i < (long)mo.indices_offset + mo.indices_count; i++) {
+      if (i < 0 || i >= n_indices) { std::fclose(f); return dbg_fail(URT_ERR_SCENE, "urt_host_dump_normals: MeshObject index range outside _Indices"); }
+      int vi = indices[i];
+      if (vi < 0 || vi >= n_vertices || vi >= n_normals) { std::fclose(f); return dbg_fail(URT_ERR_SCENE, "urt_host_dump_normals: index outside _Vertices / _Normals"); }
+      const float* v = vertices + 3 * (size_t)vi;
+      const float* n = normals + 3 * (size_t)vi;
+      float base[3], tip[3];
+      mul_point(mo.localToWorldMatrix, v[0], v[1], v[2], base);
+      mul_point(mo.localToWorldMatrix, v[0] + n[0] * 0.1f, v[1] + n[1] * 0.1f, v[2] + n[2] * 0.1f, tip);
+      std::fprintf(f, "%d %ld (%.9g, %.9g, %.9g) -> (%.9g, %.9g, %.9g)\n", k, i, base[0], base[1], base[2], tip[0], tip[1], tip[2]);
+      lines++;
+    }
+  }
+  std::fclose(f);
+  if (out_lines) *out_lines = lines;
+  return URT_OK;
+}
+
 }  // extern "C"

@@ -20,6 +20,7 @@ class RayTraceDebug:
         self.directory, self.logName, self.debugLevel = directory, logName, debugLevel     # RD:7-8 ("Debug/" + logName + ".txt", RD:30)
         self.drawSphereTree = self.drawMeshTree = True                                      # RD:9-10
         self.drawRayTrace = False                                                           # RD:11
+        self.drawNormals = True                                                             # RD:14
         self.startRay, self.testRay = (0.0, 1.0, -10.0), (0.0, 0.0, 1.0)                    # RD:12-13 (testRay is an offset from startRay, RD:130)
         os.makedirs(directory, exist_ok=True)
         self.Awake()
@@ -73,4 +74,20 @@ class RayTraceDebug:
                                                s.ctypes.data_as(C.c_void_p) if s is not None else None,
                                                e.ctypes.data_as(C.c_void_p) if e is not None else None, C.byref(n)))
         self.last_dump, self.last_dump_lines = out, n.value
+        return 0
+
+    # RD:165-183: returns 1 when drawNormals is off (as the reference does); else writes one line per index slot
+    def DrawNormals(self, mesh_objects: np.ndarray, vertices: np.ndarray, indices: np.ndarray, normals: np.ndarray) -> int:
+        if not self.drawNormals:
+            return 1
+        mo = np.ascontiguousarray(mesh_objects)
+        v = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 3)
+        ix = np.ascontiguousarray(indices, dtype=np.int32).reshape(-1)
+        nn = np.ascontiguousarray(normals, dtype=np.float32).reshape(-1, 3)
+        out = os.path.join(self.directory, f"{self.logName}_normals.txt")
+        n = C.c_int()
+        self._check(self.lib.urt_host_dump_normals(out.encode(), mo.ctypes.data_as(C.c_void_p) if len(mo) else None, len(mo),
+                                                   v.ctypes.data_as(C.c_void_p), len(v), ix.ctypes.data_as(C.c_void_p), len(ix),
+                                                   nn.ctypes.data_as(C.c_void_p), len(nn), C.byref(n)))
+        self.last_normals_dump, self.last_normals_lines = out, n.value
         return 0

@@ -226,13 +226,15 @@ class RayTraceMaster:
         host_io.write_png(path, self._converged.GetPixels())
         return path
 
-    # RM:869-878: the editor gizmos become text dumps of the two object-level heaps (RayTraceDebug.DrawBVHTree)
+    # RM:869-878: the editor gizmos become text dumps of the two object-level heaps (RayTraceDebug.DrawBVHTree) and of the normals (DrawNormals)
     def OnDrawGizmos(self):
         if self.rayDebug is not None:
             s = self.scene
             self.rayDebug.DrawBVHTree(s.mesh_bvh, self.tree_depth(len(s.mesh_objects)), 0)
             mesh_dump = getattr(self.rayDebug, "last_dump", None)
             self.rayDebug.DrawBVHTree(s.sphere_bvh, self.tree_depth(len(s.spheres)), 1)
+            if len(s.mesh_objects):
+                self.rayDebug.DrawNormals(s.mesh_objects, s.vertices, s.indices, s.normals)      # RM:875-876
             return mesh_dump, getattr(self.rayDebug, "last_dump", None)
         return None, None
 
