@@ -247,12 +247,16 @@ def main():
     clock_warmup = {"steps": 0, "ms": 0.0}
     if args.clock_warmup_ms > 0:
         tw = time.perf_counter()
-        while (time.perf_counter() - tw) * 1e3 < args.clock_warmup_ms:
+        # N > 1: every rank must run the SAME number of steps (each carries a collective): a fixed count there, the clock decides at N = 1
+        rounds = None if world == 1 else max(1, int(math.ceil(args.clock_warmup_ms / 20.0)))
+        while (rounds is None and (time.perf_counter() - tw) * 1e3 < args.clock_warmup_ms) or (rounds is not None and rounds > 0):
             for _ in range(64):
                 step()
             drain()
             fence()
             clock_warmup["steps"] += 64
+            if rounds is not None:
+                rounds -= 1
         clock_warmup["ms"] = round((time.perf_counter() - tw) * 1e3, 1)
         master._frame = 0                      # the W warm-up and K timed steps are frames 0 .. W+K-1 of the documented sequence, as without it
         master._currentSample = 0              # (sample 0 blends with alpha 1: the accumulation restarts)

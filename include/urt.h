@@ -331,6 +331,12 @@ URT_API int urt_debug_read_scene_blas(urt_context* ctx, float* nodes, int32_t* t
  * MeshObject's matrix and the positions behind its index slots are unchanged (the reference re-uploads every buffer when
  * any object moves, RM:262-336).  Reports how many MeshObject BVHs were reused / built since the context was created. */
 URT_API int urt_debug_blas_cache_stats(urt_context* ctx, uint64_t* out_reused, uint64_t* out_built);
+/* The walk table the default kernel's masked object-level phase uses for a mesh heap of <= 31 nodes (DESIGN.md §5 "masked FRONT"): header
+ * words (n_eval, levels, interior mask, exist mask | leaf_any, leaf_valid | 4 depth masks | 4 left-child shifts), 32 x {root, small_first}
+ * per heap position in pop order, then n_eval x {vmin.xyz, parent bit | vmax.xyz, position bit}.  out_words = 0 when the heap does not
+ * qualify (empty or > 31 nodes).  Host only: tests/test_walk_table.py checks the mask arithmetic against the literal walk RS:294-326. */
+URT_API int urt_debug_build_walk_table(const urt_BVHNode* heap, int n_nodes, int n_meshes, const int32_t* mesh_root, const int32_t* small_first,
+                                       float* out, int capacity_words, int* out_words);
 /* Dynamic scenes.  When the only buffer CONTENTS that changed since the scene was prepared are those of _MeshObjects, _MeshBVH, _Spheres
  * and _SphereBVH (same counts, same index range per MeshObject; data equal to what a buffer already holds counts as unchanged — the
  * reference re-uploads every list when one object moves, RM:215-230 -> 262-336), the device scene is updated in place: materials and

@@ -108,6 +108,7 @@ internal static class UrtNative {
     [DllImport(Lib)] internal static extern int urt_host_dump_bvh(string path, IntPtr nodes, int nNodes, int depth, float[] rayStart3, float[] rayEnd3, out int lines);
     [DllImport(Lib)] internal static extern int urt_host_dump_normals(string path, IntPtr meshObjects, int nMeshes, float[] vertices, int nVertices, int[] indices, int nIndices, float[] normals, int nNormals, out int lines);
     [DllImport(Lib)] internal static extern int urt_debug_refit_stats(IntPtr ctx, out ulong refittedMeshes, out ulong incrementalPreparations);
+    [DllImport(Lib)] internal static extern int urt_debug_build_walk_table(IntPtr heap, int nNodes, int nMeshes, int[] meshRoot, int[] smallFirst, float[] table, int capacityWords, out int words);
 
     // Unity's own API returns void and logs on error: the shim keeps that behaviour.
     internal static void Check(IntPtr ctx, int rc) {

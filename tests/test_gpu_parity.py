@@ -293,9 +293,15 @@ def test_masked_front_on_odd_object_heaps(gpu_ctx):
     }
     base = scenes.Scene("odd-heaps", 144, 88, 4, 1, mesh_objects=mo, vertices=vv, indices=ii, normals=nn, mesh_bvh=bvh16, sky=scenes.make_sky(64, 32))
     base = base.resized(144, 88, position=(0.3, 3.5, -9.0), fov_deg=70.0)
+    # ... and a MeshObject WITHOUT triangles whose heap leaf is hit: it sets `tests` like any leaf but is never tested itself (a table
+    # that listed it would send the ray into a triangle BVH that does not exist)
+    empty = copy.copy(base)
+    mo2 = mo.copy(); mo2[9]["indices_count"] = 0; mo2[2]["indices_count"] = 0
+    empty.mesh_objects = mo2
+    variants = [(name, base, heap) for name, heap in heaps.items()] + [("two MeshObjects without triangles", empty, bvh16)]
     try:
-        for name, heap in heaps.items():
-            sc = copy.copy(base)
+        for name, scene0, heap in variants:
+            sc = copy.copy(scene0)
             sc.mesh_bvh = heap
             o = oracle_for(sc)
             ref, oc = o.render(mode=1, threads=8, counters=True)

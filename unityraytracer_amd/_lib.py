@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "urt_shader_set_buffer", "urt_shader_set_texture", "urt_shader_set_matrix", "urt_shader_set_vector", "urt_shader_set_float",
     "urt_shader_set_int", "urt_shader_dispatch", "urt_shader_dispatch_rows", "urt_blit_add", "urt_blit", "urt_texture_pack_rows",
     "urt_texture_unpack_rows", "urt_texture_unpack_rows_on", "urt_set_option", "urt_get_counters", "urt_reset_counters", "urt_debug_build_blas", "urt_debug_get_blas", "urt_debug_blas_cache_stats",
-    "urt_debug_scene_info", "urt_debug_read_scene_blas", "urt_debug_serve_stats", "urt_debug_refit_stats", "urt_host_compute_normals", "urt_host_mesh_leaf_bounds", "urt_host_sphere_leaf_bounds", "urt_host_object_bvh_length",
+    "urt_debug_scene_info", "urt_debug_read_scene_blas", "urt_debug_serve_stats", "urt_debug_refit_stats", "urt_debug_build_walk_table", "urt_host_compute_normals", "urt_host_mesh_leaf_bounds", "urt_host_sphere_leaf_bounds", "urt_host_object_bvh_length",
     "urt_host_build_object_bvh", "urt_host_build_object_bvh_pairing", "urt_host_last_error", "urt_host_load_hdr", "urt_host_write_pfm", "urt_host_write_png",
     "urt_host_resize_rgba", "urt_host_io_last_error", "urt_host_log", "urt_host_log_scene_counts", "urt_host_log_tree_report", "urt_host_dump_bvh", "urt_host_dump_normals",
     "urt_host_debug_last_error",
@@ -104,6 +104,7 @@ def load():
         "urt_debug_scene_info": ([vp, pi, pi, pi, pf], i),
         "urt_debug_serve_stats": ([vp, vp], i),
         "urt_debug_refit_stats": ([vp, vp, vp], i),
+        "urt_debug_build_walk_table": ([vp, i, i, vp, vp, vp, i, pi], i),
         "urt_host_dump_normals": ([C.c_char_p, vp, i, vp, i, vp, i, vp, i, pi], i),
         "urt_debug_read_scene_blas": ([vp, vp, vp, vp], i),
         "urt_host_compute_normals": ([vp, i, vp, i, vp], i),

@@ -323,7 +323,7 @@ bool build_walk_table(const Buffer* heap, int n_meshes, const std::vector<int32_
   uint32_t imask = 0, exist = 0, leaf_any = 0, leaf_valid = 0, dm[4] = {0, 0, 0, 0};
   int32_t ls[4] = {0, 0, 0, 0};
   std::vector<int32_t> pos_tab(64, 0);
-  for (int p = 0; p < 32; p++) { pos_tab[(size_t)(2 * p)] = (int32_t)0x80000000; pos_tab[(size_t)(2 * p + 1)] = -1; }   // empty root
+  for (int p = 0; p < 32; p++) { pos_tab[(size_t)(2 * p)] = kEmptyMeshRoot; pos_tab[(size_t)(2 * p + 1)] = -1; }   // (positions that are never tested)
   std::vector<char> live((size_t)N, 0);                      // slab test can matter
   struct Ev { int p, parent_p; urt_BVHNode nd; };
   std::vector<Ev> ev;
@@ -337,7 +337,7 @@ bool build_walk_table(const Buffer* heap, int n_meshes, const std::vector<int32_
     bool nonempty = !(nd.vmin[0] == nd.vmax[0] && nd.vmin[1] == nd.vmax[1] && nd.vmin[2] == nd.vmax[2]);      // RS:273
     bool parent_ok = i == 0 || (live[(size_t)((i - 1) / 2)] && node((i - 1) / 2).index < 0);
     live[(size_t)i] = nonempty && parent_ok;
-    if (nd.index >= 0 && nd.index < n_meshes && mesh_root[(size_t)nd.index] != (int32_t)0x80000000) {
+    if (nd.index >= 0 && nd.index < n_meshes && mesh_root[(size_t)nd.index] != kEmptyMeshRoot) {      // a MeshObject without triangles is never tested
       leaf_valid |= 1u << p;
       pos_tab[(size_t)(2 * p)] = mesh_root[(size_t)nd.index];
       pos_tab[(size_t)(2 * p + 1)] = small_first.empty() ? -1 : small_first[(size_t)nd.index];
@@ -1755,6 +1755,27 @@ int urt_debug_blas_cache_stats(urt_context* ctx, uint64_t* out_reused, uint64_t*
   if (out_reused) *out_reused = ctx->blas_cache.hits;
   if (out_built) *out_built = ctx->blas_cache.builds;
   return URT_OK;
+}
+
+/* The masked-walk table the default kernel derives from a mesh heap of <= 31 nodes (build_walk_table above), for host-side tests:
+   out = (20 + 2 * n_eval) * 4 words; returns the number of words written through out_words, 0 when the heap does not qualify. */
+int urt_debug_build_walk_table(const urt_BVHNode* heap, int n_nodes, int n_meshes, const int32_t* mesh_root, const int32_t* small_first,
+                               float* out, int capacity_words, int* out_words) {
+  if (out_words) *out_words = 0;
+  if (n_nodes < 0 || (n_nodes > 0 && !heap) || n_meshes < 0 || (n_meshes > 0 && !mesh_root)) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "urt_debug_build_walk_table: bad arguments");
+  URT_GUARD_BEGIN
+  Buffer b; b.count = n_nodes; b.stride = URT_STRIDE_BVHNODE; b.has_data = true;
+  b.host.resize((size_t)n_nodes * URT_STRIDE_BVHNODE);
+  if (n_nodes > 0) std::memcpy(b.host.data(), heap, b.host.size());
+  std::vector<int32_t> roots(mesh_root, mesh_root + n_meshes), sf;
+  if (small_first) sf.assign(small_first, small_first + n_meshes);
+  std::vector<float> t;
+  if (!build_walk_table(n_nodes > 0 ? &b : nullptr, n_meshes, roots, sf, t)) return URT_OK;
+  if ((int)t.size() > capacity_words || !out) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "urt_debug_build_walk_table: output buffer too small");
+  std::memcpy(out, t.data(), t.size() * sizeof(float));
+  if (out_words) *out_words = (int)t.size();
+  return URT_OK;
+  URT_GUARD_END(nullptr)
 }
 
 int urt_debug_refit_stats(urt_context* ctx, uint64_t* out_refitted_meshes, uint64_t* out_incremental_preparations) {
