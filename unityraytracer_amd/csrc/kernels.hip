@@ -390,8 +390,18 @@ __device__ __forceinline__ v3 sample_sky(const DevScene& S, float u, float v) {
   float x0f = f_floor(x), y0f = f_floor(y);
   float fx = x - x0f, fy = y - y0f;
   int x0 = (int)x0f, y0 = (int)y0f;
-  x0 %= W; if (x0 < 0) x0 += W;
-  y0 %= H; if (y0 < 0) y0 += H;
+  // repeat wrap.  The sky lookup's (u, v) lie in [-0.5, 0.5] x [-1, 0] (RS:424-425), so the texel index is within one period of the image:
+  // one conditional add gives what the integer modulo (two dozen instructions each) gives; anything else takes the modulo
+#ifndef URT_SKY_FASTWRAP
+#define URT_SKY_FASTWRAP 1
+#endif
+  if (URT_SKY_FASTWRAP && (unsigned)x0 + (unsigned)W < 2u * (unsigned)W && (unsigned)y0 + (unsigned)H < 2u * (unsigned)H) {
+    if (x0 < 0) x0 += W;
+    if (y0 < 0) y0 += H;
+  } else {
+    x0 %= W; if (x0 < 0) x0 += W;
+    y0 %= H; if (y0 < 0) y0 += H;
+  }
   int x1 = x0 + 1; if (x1 == W) x1 = 0;
   int y1 = y0 + 1; if (y1 == H) y1 = 0;
   float4 c00 = S.sky[(size_t)y0 * W + x0], c10 = S.sky[(size_t)y0 * W + x1];
