@@ -45,6 +45,9 @@ for (w, h, b), wpc in itertools.product(((1920, 1080, 8),), (20,)):
         print(f"   REFILL: {fs[:, 2].mean():7.1f} refills/wave; work-counter hand-out {fs[:, 0].sum() / 100 / life.sum() * 100:5.1f} % of wave time ({fs[:, 0].sum() / 100 / fs[:, 2].sum():5.2f} us each), "
               f"camera rays {fs[:, 1].sum() / 100 / life.sum() * 100:5.1f} % ({fs[:, 1].sum() / 100 / fs[:, 2].sum():5.2f} us each); "
               f"unaccounted {(1 - (t[:, 0:3].sum() + (fs[:, 0].sum() + fs[:, 1].sum()) / 100) / life.sum()) * 100:5.1f} %")
+        steps = trips[:, 3].sum()
+        print(f"   BLAS vote: {fs[:, 4].sum() / max(1, steps):5.1f} lanes take part per step of {lanes[:, 3].sum() / max(1, steps):5.1f} active; node trips {fs[:, 5].sum() / max(1, steps) * 100:5.1f} % of steps, "
+              f"{fs[:, 6].sum() / max(1, fs[:, 5].sum()):5.1f} lanes wait at a leaf per node trip")
     if fs[:, 3].sum() > 0:                                       # listed FRONT: where its time goes
         ft = t[:, 0].sum()
         print(f"   FRONT split: heap walk {fs[:, 0].sum() / 100 / ft * 100:5.1f} % ({fs[:, 0].sum() / 100 / fs[:, 3].sum():6.2f} us per walk, {fs[:, 6].sum() / fs[:, 3].sum():5.1f} fresh lanes), "

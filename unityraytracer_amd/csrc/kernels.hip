@@ -1279,6 +1279,7 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
   unsigned long long dr_trips[4] = {0, 0, 0, 0}, dr_t[3] = {0, 0, 0}, dr_live = 0, dr_lanes3 = 0;   // after the work ran dry
   unsigned long long fs_arr[7] = {0, 0, 0, 0, 0, 0, 0};   // listed FRONT: time in the heap walk / single-leaf tests / BVH-top walks, walks, single-leaf rounds, top walks, fresh lanes walked
   unsigned long long rf_t[3] = {0, 0, 0};                  // refill: time in the work-counter hand-out (the atomic's round trip), in the camera rays, refills
+  unsigned long long bl_part[3] = {0, 0, 0};               // BLAS loop: lanes that took part in their trip (sum), node trips, lanes at a leaf during node trips (sum)
 #endif
 
   for (;;) {
@@ -1410,6 +1411,9 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
 #define URT_VOTE_DEN 2
 #endif
         bool node_trip = URT_VOTE_DEN * nI >= URT_VOTE_NUM * nA;
+#ifdef URT_STAMPS
+        bl_part[0] += (unsigned long long)(node_trip ? nI : nA - nI); bl_part[1] += node_trip ? 1 : 0; bl_part[2] += (unsigned long long)(node_trip ? nA - nI : 0);
+#endif
 #ifdef URT_MINORITY                          // A/B build: when the minority kind has held >= 40 % of the active lanes for two trips, it gets this trip
         {
           int nMin = min(nI, nA - nI);
@@ -1490,7 +1494,7 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
     for (int q = 0; q < 4; q++) { sp_[w + q] = ph_t[q]; sp_[w + 4 + q] = ph_lanes[q]; sp_[w + 8 + q] = ph_trips[q]; }
     sp_[w + 12] = t_begin; sp_[w + 13] = wall_clock64(); sp_[w + 14] = t_dry; sp_[w + 15] = __builtin_amdgcn_s_memtime() - c_begin;
     for (int q = 0; q < 7; q++) sp_[w + 25 + q] = fs_arr[q];
-    if (FMODE < 2) { sp_[w + 25] = rf_t[0]; sp_[w + 26] = rf_t[1]; sp_[w + 27] = rf_t[2]; sp_[w + 28] = 0; }     // (single-mesh instantiations: no FRONT split, the refill's instead)
+    if (FMODE < 2) { sp_[w + 25] = rf_t[0]; sp_[w + 26] = rf_t[1]; sp_[w + 27] = rf_t[2]; sp_[w + 28] = 0; sp_[w + 29] = bl_part[0]; sp_[w + 30] = bl_part[1]; sp_[w + 31] = bl_part[2]; }     // (single-mesh instantiations: no FRONT split, the refill's instead)
   }
 #endif
   if (watchdog && (threadIdx.x & 63) == 0) report_watchdog(P, ctr);
