@@ -381,6 +381,9 @@ __device__ __forceinline__ v3 sample_hemisphere(v3 normal, float inv_alpha1, flo
 typedef float f4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void st_result(float4* p, float4 v) {
   f4v q = {v.x, v.y, v.z, v.w};
+#ifdef URT_PROBE_NOSTORE                     // timing probe only (wrong images): what do the Result stores cost the waves that issue them?
+  if (v.x != 1234567.0f) return;
+#endif
   __builtin_nontemporal_store(q, (f4v*)p);
 }
 
