@@ -5,10 +5,10 @@ cd "$(dirname "$0")/../unityraytracer_amd" || exit 1
 OUT=${1:-/tmp/urt_remarks.so}; shift
 # KERNELS_ONLY=1: compile csrc/kernels.hip alone (-c): the trace kernels' numbers in half a minute
 if [ -n "$KERNELS_ONLY" ]; then
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -fvisibility=hidden -pthread -Xarch_host -march=x86-64-v3 \
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -fvisibility=hidden -pthread -Xarch_host -march=x86-64-v3 -Xarch_device -fno-slp-vectorize \
     -Wall -Wno-unused-function -Rpass-analysis=kernel-resource-usage "$@" -c csrc/kernels.hip -o "$OUT" 2> /tmp/urt_remarks.log
 else
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -fvisibility=hidden -pthread -Xarch_host -march=x86-64-v3 \
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -fvisibility=hidden -pthread -Xarch_host -march=x86-64-v3 -Xarch_device -fno-slp-vectorize \
   -Wall -Wno-unused-function -Rpass-analysis=kernel-resource-usage "$@" -o "$OUT" \
   csrc/kernels.hip csrc/lbvh.hip csrc/refit.hip csrc/qnodes.hip csrc/context.cpp csrc/blas_builder.cpp csrc/host_scene.cpp csrc/host_io.cpp csrc/host_debug.cpp csrc/group.cpp 2> /tmp/urt_remarks.log
 fi

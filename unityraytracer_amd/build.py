@@ -15,6 +15,7 @@ HIPCC_FLAGS = [
     "-ffp-contract=off",            # normative arithmetic: no implicit fma (include/urt_math.h)
     "-fPIC", "-shared", "-fvisibility=hidden", "-pthread",
     "-Xarch_host", "-march=x86-64-v3",   # inline hardware fma for the host-side vertex pre-transform
+    "-Xarch_device", "-fno-slp-vectorize",   # v_pk_fma_f32 issues at half rate on gfx950 and its operand pairs cost moves: -0.5 .. -1.4 % frame time (r3_ab_cnodes_noslp.log)
     "-Wall", "-Wno-unused-function",
 ]
 SOURCES = ["kernels.hip", "lbvh.hip", "refit.hip", "qnodes.hip", "context.cpp", "blas_builder.cpp", "host_scene.cpp", "host_io.cpp", "host_debug.cpp", "group.cpp"]
