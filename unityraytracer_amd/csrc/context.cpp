@@ -636,7 +636,7 @@ int prepare_scene(urt_context* ctx) {
   ctx->tlas_stack = std::max(2, lv + 1);
   if (n_blas_nodes >= (1u << 26)) return fail(ctx, URT_ERR_SCENE, "triangle BVH larger than 2^26 nodes (4 GiB)");   // kernels address nodes by 32-bit byte offsets
   if ((uint64_t)n_tris * 48ull >= (1ull << 32)) return fail(ctx, URT_ERR_SCENE, "more than 2^32 / 48 triangles (4 GiB of triangle records)");   // 32-bit byte offsets as well
-  ctx->blas_stack = std::max(2, blas_max_depth + 1);
+  ctx->blas_stack = std::max(2, blas_max_depth + 1) + 1;      // + the sentinel entry below the stack (kernels.hip blas_node_eval_ptr)
   ctx->n_blas_nodes = (int)std::min<size_t>(0x7fffffff, n_blas_nodes);
   ctx->n_scene_tris = (int)n_tris; ctx->scene_max_depth = blas_max_depth;
   // a ray with NaN components passes every slab test and walks the whole tree once: (nodes + leaves) trips per lane, and the

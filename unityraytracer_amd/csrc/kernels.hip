@@ -218,6 +218,33 @@ __device__ __forceinline__ int32_t blas_node_eval_flat(float4 q0, float4 q1, flo
   return nxt;
 }
 
+// The traversal loop of k_sched keeps the stack as a POINTER to its top entry (the one a pop returns) and a sentinel kBlasDone in
+// entry 0 (written once per lane; a traversal starts at height 1): no address arithmetic per step (the far child goes to top[64], an
+// immediate offset), no empty-stack test (popping the sentinel ends the traversal).  On this chip a compare, a select or a
+// three-operand integer add each cost 1.8 fma (profiles/r03_logs/r3_valu_table_microbench.log): six of them per node step go.
+__device__ __forceinline__ int32_t blas_node_select_ptr(bool h0, bool h1, float tn0, float tn1, int32_t c0, int32_t c1, int32_t below, int*& top_) {
+  bool both = h0 && h1, none = !h0 && !h1;
+  bool first1 = h1 && (!h0 || tn1 < tn0);          // child 1 is visited first: the only hit, or the nearer of two (ties: child 0)
+  top_[64] = first1 ? c0 : c1;                      // the far child, where a push would put it
+  int32_t nxt = none ? below : (first1 ? c1 : c0);
+  top_ += both ? 64 : (none ? -64 : 0);
+  return nxt;
+}
+__device__ __forceinline__ int32_t blas_node_eval_ptr(float4 q0, float4 q1, float4 q2, float4 q3, const BlasRay& R, float tbest, int*& top_) {
+  int32_t below = *top_;
+  float a1x = f_fma(q0.x, R.idir.x, R.nop.x), a2x = f_fma(q0.w, R.idir.x, R.nom.x);
+  float a1y = f_fma(q0.y, R.idir.y, R.nop.y), a2y = f_fma(q1.x, R.idir.y, R.nom.y);
+  float a1z = f_fma(q0.z, R.idir.z, R.nop.z), a2z = f_fma(q1.y, R.idir.z, R.nom.z);
+  float tn0 = f_max(f_max(f_min(a1x, a2x), f_min(a1y, a2y)), f_max(f_min(a1z, a2z), 0.0f));
+  float tf0 = f_min(f_min(f_max(a1x, a2x), f_max(a1y, a2y)), f_min(f_max(a1z, a2z), tbest));
+  float b1x = f_fma(q1.z, R.idir.x, R.nop.x), b2x = f_fma(q2.y, R.idir.x, R.nom.x);
+  float b1y = f_fma(q1.w, R.idir.y, R.nop.y), b2y = f_fma(q2.z, R.idir.y, R.nom.y);
+  float b1z = f_fma(q2.x, R.idir.z, R.nop.z), b2z = f_fma(q2.w, R.idir.z, R.nom.z);
+  float tn1 = f_max(f_max(f_min(b1x, b2x), f_min(b1y, b2y)), f_max(f_min(b1z, b2z), 0.0f));
+  float tf1 = f_min(f_min(f_max(b1x, b2x), f_max(b1y, b2y)), f_min(f_max(b1z, b2z), tbest));
+  return blas_node_select_ptr(tn0 <= tf0, tn1 <= tf1, tn0, tn1, as_int(q3.x), as_int(q3.y), below, top_);
+}
+
 // The same step on a 32-byte QUANTIZED node (csrc/qnodes.hip): two dwordx4 loads instead of four.  The twelve planes are 16-bit grid
 // coordinates q; a plane's slab value is t = (origin + q cell - (o +- pad)) / d = fma(Q, S, B) with Q = 2^23 + q — built in ONE
 // instruction per plane by putting q into the mantissa of 2^23 (0x4B000000 | q) —, S = cell / d and B = (origin - (o +- pad)) / d - 2^23 S
@@ -235,8 +262,8 @@ __device__ __forceinline__ QRay make_qray(const BlasRay& R, float4 forg, float4 
 }
 __device__ __forceinline__ float q_lo16(float w) { return as_float((int)(((unsigned int)as_int(w) & 0xffffu) | 0x4B000000u)); }
 __device__ __forceinline__ float q_hi16(float w) { return as_float((int)__builtin_amdgcn_alignbit(0x4B00u, (unsigned int)as_int(w), 16u)); }
-__device__ __forceinline__ int32_t qnode_eval_flat(float4 u0, float4 u1, const QRay& Q, float tbest, int* stk, int& sp) {
-  int below = stk[max(sp - 1, 0) * 64];
+__device__ __forceinline__ int32_t qnode_eval_ptr(float4 u0, float4 u1, const QRay& Q, float tbest, int*& top_) {
+  int32_t below = *top_;
   // child 0: lo (u0.x lo16, u0.x hi16, u0.y lo16) hi (u0.y hi16, u0.z lo16, u0.z hi16); child 1: the same from u0.w, u1.x, u1.y
   float a1x = f_fma(q_lo16(u0.x), Q.S.x, Q.Bp.x), a2x = f_fma(q_hi16(u0.y), Q.S.x, Q.Bm.x);
   float a1y = f_fma(q_hi16(u0.x), Q.S.y, Q.Bp.y), a2y = f_fma(q_lo16(u0.z), Q.S.y, Q.Bm.y);
@@ -248,15 +275,7 @@ __device__ __forceinline__ int32_t qnode_eval_flat(float4 u0, float4 u1, const Q
   float b1z = f_fma(q_lo16(u1.x), Q.S.z, Q.Bp.z), b2z = f_fma(q_hi16(u1.y), Q.S.z, Q.Bm.z);
   float tn1 = f_max(f_max(f_min(b1x, b2x), f_min(b1y, b2y)), f_max(f_min(b1z, b2z), 0.0f));
   float tf1 = f_min(f_min(f_max(b1x, b2x), f_max(b1y, b2y)), f_min(f_max(b1z, b2z), tbest));
-  bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
-  int32_t c0 = as_int(u1.z), c1 = as_int(u1.w);
-  bool both = h0 && h1, none = !h0 && !h1;
-  bool first1 = h1 && (!h0 || tn1 < tn0);
-  stk[sp * 64] = first1 ? c0 : c1;
-  int32_t popped = sp > 0 ? below : kBlasDone;
-  int32_t nxt = none ? popped : (first1 ? c1 : c0);
-  sp += both ? 1 : (none && sp > 0 ? -1 : 0);
-  return nxt;
+  return blas_node_select_ptr(tn0 <= tf0, tn1 <= tf1, tn0, tn1, as_int(u1.z), as_int(u1.w), below, top_);
 }
 
 // One interior-node step: slab-test both children against [0, tbest], descend into the nearer hit child (ties: child 0),
@@ -826,7 +845,8 @@ struct FrontLds {
   const int32_t* small_first = nullptr;  // [n_meshes] first triangle of MeshObject m in small_tris, or -1
 };
 
-template <bool COUNT, bool TOPF = false, bool RAYS = true>
+// SP0: the height an empty triangle-BVH stack has for the caller (1 = a sentinel sits in entry 0: k_sched)
+template <bool COUNT, bool TOPF = false, bool RAYS = true, int SP0 = 0>
 __device__ __forceinline__ bool trace_front(const DevScene& S, bool fresh, v3 o, v3 d, HitRec& best, int& check, bool& seen,
                                             int* tl, int stride, int32_t& cur, LocalCounters& lc, const FrontLds& L = FrontLds(),
                                             const float4* top = nullptr, int top_nodes = 0, int* bl = nullptr, int* sp_out = nullptr) {
@@ -863,7 +883,7 @@ __device__ __forceinline__ bool trace_front(const DevScene& S, bool fresh, v3 o,
         else test_leaf<COUNT>(S, root, o, d, best, bi_local, lc);
       } else if (root != kEmptyMeshRoot) {
         if (TOPF) {
-          int sp = 0;
+          int sp = SP0;
           if (root < top_nodes) {
             BlasRay R = blas_ray(o, d);    // recomputed per MeshObject entered: keeping it live across the heap walk costs more (spills)
             do root = blas_node_step_top<COUNT>(top, root, R, best.t, bl, sp, lc); while (root >= 0 && root < top_nodes);
@@ -932,7 +952,7 @@ __device__ __forceinline__ int list_get(const int* tl, int j) {
 #define URT_FS_ARG
 #define URT_FS(stmt)
 #endif
-template <bool COUNT>
+template <bool COUNT, int SP0 = 0>
 __device__ __forceinline__ int front_listed(const DevScene& S, const FrameParams& P, bool mine, bool fresh, v3 o, v3 d, HitRec& best, int& cs,
                                             int* tl, int32_t& cur, LocalCounters& lc, const FrontLds& L, const float4* top, int* bl, int& sp,
                                             unsigned int& wave_rays URT_FS_DECL) {
@@ -1000,7 +1020,7 @@ __device__ __forceinline__ int front_listed(const DevScene& S, const FrameParams
     if (wballot(has) == 0) break;
     URT_FS(fs[5]++;)
     if (has) {
-      sp = 0;
+      sp = SP0;
       if (root < P.top_nodes) {
         BlasRay R = blas_ray(o, d);
         do root = blas_node_step_top<COUNT>(top, root, R, best.t, bl, sp, lc); while (root >= 0 && root < P.top_nodes);
@@ -1053,7 +1073,7 @@ struct WalkLds {
   const int* pos_tab = nullptr;        // [2p] triangle-BVH root of the object at position p, [2p+1] its first triangle in small_tris or -1
   const float4* eval = nullptr;        // [2e] vmin.xyz, position bit of the parent (0: the root)  [2e+1] vmax.xyz, position bit
 };
-template <bool COUNT>
+template <bool COUNT, int SP0 = 0>
 __device__ __forceinline__ int front_masked(const DevScene& S, const FrameParams& P, bool mine, bool fresh, v3 o, v3 d, HitRec& best, int& cs,
                                             int* tl, int32_t& cur, LocalCounters& lc, const FrontLds& L, const WalkLds& W, const float4* top, int* bl, int& sp,
                                             unsigned int& wave_rays URT_FS_DECL) {
@@ -1126,7 +1146,7 @@ __device__ __forceinline__ int front_masked(const DevScene& S, const FrameParams
     if (wballot(has) == 0) break;
     URT_FS(fs[5]++;)
     if (has) {
-      sp = 0;
+      sp = SP0;
       if (root < P.top_nodes) {
         BlasRay R = blas_ray(o, d);
         do root = blas_node_step_top<COUNT>(top, root, R, best.t, bl, sp, lc); while (root >= 0 && root < P.top_nodes);
@@ -1272,7 +1292,8 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
   // trace state (one Trace() in flight per lane)
   HitRec best; best.t = URT_INF; best.kid = 0; best.u = 0; best.v = 0;
   int cs = 0;                                    // object-level heap walk (RS:294-326): stack height `check` | never-reset `tests` flag << 8
-  int32_t cur = kBlasDone; int sp = 0, best_i = -1;   // triangle-BVH cursor of the current MeshObject
+  bl[0] = kBlasDone;                                  // the sentinel below every traversal stack of this lane (blas_node_eval_ptr): heights start at 1
+  int32_t cur = kBlasDone; int sp = 1, best_i = -1;   // triangle-BVH cursor of the current MeshObject
   unsigned int wave_iters = 0, wave_rays = 0;
   bool watchdog = false;
 #ifdef URT_STAMPS
@@ -1362,17 +1383,17 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
       if (FMODE < 2) wave_rays += (unsigned int)__popcll(wballot(st == ST_FRONT));     // Trace() invocations (RS:454), counted per wave
       if (FMODE >= 2) {
         bool mine = st == ST_FRONT || st == ST_RESUME;
-        int r = FMODE == 3 ? front_masked<COUNT>(S, P, mine, st == ST_FRONT, o, d, best, cs, tl, cur, lc, L, W, top, bl, sp, wave_rays URT_FS_ARG)
-                           : front_listed<COUNT>(S, P, mine, st == ST_FRONT, o, d, best, cs, tl, cur, lc, L, top, bl, sp, wave_rays URT_FS_ARG);
+        int r = FMODE == 3 ? front_masked<COUNT, 1>(S, P, mine, st == ST_FRONT, o, d, best, cs, tl, cur, lc, L, W, top, bl, sp, wave_rays URT_FS_ARG)
+                           : front_listed<COUNT, 1>(S, P, mine, st == ST_FRONT, o, d, best, cs, tl, cur, lc, L, top, bl, sp, wave_rays URT_FS_ARG);
         if (mine && r != 2) {
           if (r == 1) { best_i = -1; st = ST_BLAS; }
           else st = best.t < URT_INF ? ST_SHADE : ST_SKY;
         }
       } else if (st == ST_FRONT || st == ST_RESUME) {
-        sp = 0;
+        sp = 1;
         int check = cs & 0xff; bool seen = (cs >> 8) != 0;
-        bool need = FMODE == 1 ? trace_front<COUNT, true, false>(S, st == ST_FRONT, o, d, best, check, seen, tl, 64, cur, lc, L, top, P.top_nodes, bl, &sp)
-                               : trace_front<COUNT, false, false>(S, st == ST_FRONT, o, d, best, check, seen, tl, 64, cur, lc, L);
+        bool need = FMODE == 1 ? trace_front<COUNT, true, false, 1>(S, st == ST_FRONT, o, d, best, check, seen, tl, 64, cur, lc, L, top, P.top_nodes, bl, &sp)
+                               : trace_front<COUNT, false, false, 1>(S, st == ST_FRONT, o, d, best, check, seen, tl, 64, cur, lc, L);
         cs = check | (seen ? 256 : 0);
         if (need) { best_i = -1; st = ST_BLAS; }
         else st = best.t < URT_INF ? ST_SHADE : ST_SKY;
@@ -1391,6 +1412,7 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
       // votes are then single compares whose result IS the ballot (kBlasDone is negative, so c >= 0 <=> an interior node of a
       // participating lane), and the loop control sits in scalar registers (the limits are pinned there).
       int32_t c = mine ? cur : kBlasDone;
+      int* spp = bl + (sp - 1) * 64;                         // the top entry of the lane's stack: what a pop returns (height 1 = the sentinel)
       int budget = __builtin_amdgcn_readfirstlane((int)min(P.watchdog_steps, 0x7fffffffu));   // trips left before the watchdog ends this phase (counted down: no kernel argument in the loop)
       const int exit_s = __builtin_amdgcn_readfirstlane(exit_below);
       QRay Q;
@@ -1429,7 +1451,7 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
             if (c >= 0) {
               const float4* n = (const float4*)((const char*)(S.blas_qnodes + 2) + ((uint32_t)c << 5));
               float4 u0 = n[0], u1 = n[1];
-              c = qnode_eval_flat(u0, u1, Q, best.t, bl, sp);
+              c = qnode_eval_ptr(u0, u1, Q, best.t, spp);
             }
           } else if (c >= 0) {
             if (COUNT) lc.blas_nodes++;
@@ -1438,14 +1460,14 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
 #ifdef URT_EXTRA_NODE_LOADS                // A/B probe: how sensitive is the loop to vector-memory instructions per node step?
             { const float4* n2 = (const float4*)((const char*)S.blas_nodes + ((uint32_t)(c > 0 ? c - 1 : c + 1) << 6)); float4 x0 = n2[0], x1 = n2[1]; asm volatile("" :: "v"(x0.x), "v"(x1.x)); }
 #endif
-            c = blas_node_eval_flat(q0, q1, q2, q3, R, best.t, bl, sp);
+            c = blas_node_eval_ptr(q0, q1, q2, q3, R, best.t, spp);
           }
         } else if (c < 0 && c != kBlasDone) {
           test_leaf<COUNT>(S, c, o, d, best, best_i, lc);
-          c = blas_pop(bl, sp);
+          c = *spp; spp -= 64;                               // pop (the sentinel ends the traversal)
         }
       }
-      if (mine) cur = c;
+      if (mine) { cur = c; sp = ((int)(spp - bl) >> 6) + 1; }
       // back to the heap walk (RS:323-325 continues) — or, when nothing of Trace() is left to do (empty object-level stack and
       // no spheres), straight to shading: saves the path one scheduling round trip per bounce
       if (mine && cur == kBlasDone) st = ((FMODE == 3 ? cs : (cs & 0xff)) == 0 && S.n_spheres == 0) ? (best.t < URT_INF ? ST_SHADE : ST_SKY) : ST_RESUME;
