@@ -114,6 +114,20 @@ def test_culled_mode_equals_brute_force(built_library):
     assert np.array_equal(brute.view(np.uint32), own.view(np.uint32))
 
 
+def test_culled_mode_equals_brute_force_on_a_chain_shaped_bvh(built_library):
+    """scenes.deep_chain_scene: coordinates from 1 to 4e18 in one MeshObject (the build-time pad is 2^-16 of that: every near box swallows the
+    camera) and a BVH that is one long chain — brute force and the culled walk must still agree, and the product BVH must be valid."""
+    sc = scenes.deep_chain_scene()
+    o = pyoracle.Oracle(sc)
+    brute, cb = o.render(mode=0, threads=8, counters=True)
+    nodes, tri, root, _, depth = debug_build_blas(sc.mesh_objects, sc.vertices, sc.indices)
+    assert validate(sc, nodes, tri, root) <= depth and depth >= 10
+    o.set_blas(nodes, tri, root)
+    culled, cc = o.render(mode=1, threads=8, counters=True)
+    assert np.array_equal(brute.view(np.uint32), culled.view(np.uint32))
+    assert cc["hit_tri"] == cb["hit_tri"] > 0 and np.isfinite(culled).all()
+
+
 def test_culled_mode_equals_brute_force_on_dense_mesh_crop(built_library):
     sc = scenes.config3(160, 90, slices=60, stacks=47, sky=scenes.make_sky(64, 32))      # 5,520 triangles
     o = pyoracle.Oracle(sc)

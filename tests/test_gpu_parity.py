@@ -149,6 +149,30 @@ def test_deep_stacks_use_the_large_lds_launch_path(gpu_ctx):
         gpu_ctx.set_option("stack_pad", 0)
 
 
+def test_chain_shaped_triangle_bvh_fills_the_traversal_stack(gpu_ctx):
+    """A triangle BVH that is a chain (one triangle per leaf, every split peels off the far end) is as deep as it has leaves, and a ray
+    down its axis has the far child of EVERY level on its stack at once: the per-lane LDS stacks (depth + free slot + the sentinel
+    entry of the pointer-form loop, kernels.hip blas_node_eval_ptr) are used to the last entry.  Pixels and counters == oracle in every mode."""
+    sc = scenes.deep_chain_scene()
+    try:
+        gpu_ctx.set_option("blas_leaf_max", 1)                 # (process-wide builder setting: the oracle's copy of the BVH follows)
+        m = RayTraceMaster(gpu_ctx, sc); m.OnRenderImage()
+        _, _, _, info = gpu_ctx.read_scene_blas(len(sc.mesh_objects))
+        m.OnDisable()
+        assert info["max_depth"] >= 22, info              # (the product builder: 24 levels for the 40 triangles)
+        o = oracle_for(sc)
+        ref, oc = o.render(mode=1, threads=8, counters=True)
+        assert oc["hit_tri"] > 0
+        for mode in (3, 0, 2, 4, 5):
+            gpu, _, gc = render_gpu(gpu_ctx, sc, mode, count=True)
+            assert_same(gpu, ref, f"chain BVH, mode {mode}")
+            assert gc["watchdog_trips"] == 0
+            for k in ("rays", "blas_nodes", "tri_tests"):
+                assert gc[k] == oc[k], (mode, k, gc[k], oc[k])
+    finally:
+        gpu_ctx.set_option("blas_leaf_max", 4)
+
+
 @pytest.mark.parametrize("k", [1, 2, 3, 4])
 def test_path_pool_sizes_bit_exact(gpu_ctx, k):
     sc = scenes.mixed_test_scene(200, 120)

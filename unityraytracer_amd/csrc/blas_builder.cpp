@@ -45,7 +45,12 @@ struct Box {
 };
 
 constexpr int kBins = 16;
-int g_leaf_max = 4;              // SAH leaves (tunable: URT_BLAS_LEAF_MAX / urt_set_option "blas_leaf_max")
+int leaf_max_from_env() {
+  const char* e = std::getenv("URT_BLAS_LEAF_MAX");
+  int v = e ? std::atoi(e) : 4;
+  return v >= 1 && v <= 8 ? v : 4;
+}
+int g_leaf_max = leaf_max_from_env();   // SAH leaves (tunable: URT_BLAS_LEAF_MAX at load time / urt_set_option "blas_leaf_max")
 constexpr int kLeafHardMax = 8;  // encoding limit (3 bits)
 constexpr int kForkMinPrims = 8192;   // subtrees at least this big may get a thread of their own
 

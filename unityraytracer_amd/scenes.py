@@ -539,6 +539,24 @@ CONFIGS = {"C1": config1, "C2": config2, "C3": config3, "C4": config4, "C5": con
 
 
 # --- the reference's own scenes (tests/golden/scene_*.json, mined from Assets/Scenes/*.unity by tests/golden/make_scene_fixtures.py) ---
+def deep_chain_scene(width=96, height=64, n=40, ratio=3.0, grow=1.8) -> Scene:
+    """One MeshObject whose triangles stand behind each other at geometrically growing distances (x ratio) and sizes (x grow): every SAH
+    split peels off the far end, so with one triangle per leaf the BVH is a chain as deep as it has triangles — and a camera ray descends
+    into the near (interior) child at every level with the far leaf pushed: the stack holds one entry per level.
+    Exercises the depth of the traversal stacks (tests/test_gpu_parity.py)."""
+    vs, ts = [], []
+    for k in range(n):
+        z = -8.0 + ratio ** k
+        s = 0.2 * grow ** k
+        base = len(vs)
+        vs += [(-s + 0.01 * k, 1 - s, z), (0.01 * k, 1 + s, z), (s + 0.01 * k, 1 - s, z)]     # counter-clockwise seen from the camera (-z)
+        ts.append((base, base + 1, base + 2))
+    b = MeshSceneBuilder()
+    b.add(np.array(vs, np.float32), np.array(ts, np.int32), trs(), _params((0.8, 0.6, 0.4), (0.1, 0.1, 0.1), (0, 0, 0), 0.3))
+    mo, vv, ii, nn, bvh = b.finish()
+    return Scene("deep-chain", width, height, 3, 1, mesh_objects=mo, vertices=vv, indices=ii, normals=nn, mesh_bvh=bvh, sky=make_sky(64, 32))
+
+
 def trs_quat(translate=(0, 0, 0), quat=(0, 0, 0, 1), scale=(1, 1, 1)) -> np.ndarray:
     """Matrix4x4.TRS(position, rotation, scale) as 16 floats in Unity memory order (column-major); quat = (x, y, z, w)."""
     x, y, z, w = (float(c) for c in quat)
