@@ -190,7 +190,8 @@ typedef struct urt_counters {
  *                  trips — auto / 1: by mask arithmetic over the heap when it has <= 31 nodes, else as a list when <= 12 MeshObjects; 2: always the list), "lds_tlas" (0/1: small object-level tables in LDS),
  *          mode 4: "pool_k" (1..4), "pool_refill", "pool_blas_min" (1..256), "pool_blas_exit", "pool_inloop",
  *                  "pool_other_min" (1..64),
- *          "blas_leaf_max" (1..8: triangles per BVH leaf; rebuilds the BVH),
+ *          "blas_leaf_max" (1..8: triangles per BVH leaf, default 4 or the environment variable URT_BLAS_LEAF_MAX read when the
+ *          library is loaded — a process-wide builder setting; rebuilds the BVH),
  *          "stack_pad" (0..96: test hook, unused extra entries per traversal stack -> the > 64 KiB LDS launch path),
  *          "qnodes" (0 off, the default | 1 on | -1 on unless some MeshObject spans fewer than 1024 grid cells: the traversal loop of the default
  *                    kernel reads 32-byte quantized copies of the triangle-BVH nodes — two vector loads per node step instead of four; conservative
