@@ -141,7 +141,9 @@ struct urt_context {
   int opt_serve_refill = 16;                // kernel_mode 5: idle lanes of the traversal service that trigger a claim of waiting rays
   int opt_front_list = -1;                  // kernel_mode 3: listed FRONT for scenes of <= 12 MeshObjects (-1 auto = on, 0 off)
   int opt_shade_split = -1;                 // kernel_mode 3: -1 = auto (= split: measured better or equal on C2-C5), 0 = surface hits and misses shaded in one trip
-  int opt_tile_order = 0;                   // persistent modes: order in which the frame's tiles are handed out
+  int opt_tile_order = 1;                   // persistent modes: order in which the frame's tiles are handed out.  1 = top strip first: a launch then ENDS with the bottom
+                                            // rows, which in a scene on a ground plane hold the short paths without traversal (measured: C2 -3.5 .. -9 %, C3 -1.5 .. -4 %, C3D / C4 / C5 +-0.3 %,
+                                            // profiles/r03_logs/r3_probe_tile_order.log); any order draws the same pixels
   int opt_lds_tlas = 1;                     // kernel_mode 3: object-level heaps, roots and spheres in LDS when small
   int opt_top_front = -1;                   // kernel_mode 3: top-of-forest walk inside the object-level phase (-1 = when the scene has several meshes)
   int opt_top_nodes = 64;                   // kernel_mode 3: triangle-BVH nodes kept in LDS (0 = none)
