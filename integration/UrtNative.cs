@@ -108,6 +108,18 @@ internal static class UrtNative {
     [DllImport(Lib)] internal static extern int urt_host_dump_bvh(string path, IntPtr nodes, int nNodes, int depth, float[] rayStart3, float[] rayEnd3, out int lines);
     [DllImport(Lib)] internal static extern int urt_host_dump_normals(string path, IntPtr meshObjects, int nMeshes, float[] vertices, int nVertices, int[] indices, int nIndices, float[] normals, int nNormals, out int lines);
     [DllImport(Lib)] internal static extern int urt_debug_refit_stats(IntPtr ctx, out ulong refittedMeshes, out ulong incrementalPreparations);
+    [DllImport(Lib)] internal static extern int urt_host_build_object_bvh_pairing(IntPtr leaves, int nObjects, IntPtr outNodes, int capacity);   // RM:459-722's pairing builder, restated
+    [DllImport(Lib)] internal static extern int urt_host_resize_rgba(float[] src, int width, int height, [Out] float[] dst, int newWidth, int newHeight);
+    [DllImport(Lib)] internal static extern IntPtr urt_host_last_error();          // const char* (thread-local, like the two below)
+    [DllImport(Lib)] internal static extern IntPtr urt_host_io_last_error();
+    [DllImport(Lib)] internal static extern IntPtr urt_host_debug_last_error();
+    // ---- introspection (what tests/ use; not needed by RM) --------------------------------------------------------------
+    [DllImport(Lib)] internal static extern int urt_debug_build_blas(IntPtr meshObjects, int nMeshes, float[] vertices, int nVertices, int[] indices, int nIndices, out int nNodes, out int nTris, out int maxDepth);
+    [DllImport(Lib)] internal static extern int urt_debug_get_blas([Out] float[] nodes, [Out] int[] triIndex, [Out] int[] meshRoot, [Out] int[] meshFirstTri);
+    [DllImport(Lib)] internal static extern int urt_debug_scene_info(IntPtr ctx, out int nNodes, out int nTris, out int maxDepth, out float prepareMs);
+    [DllImport(Lib)] internal static extern int urt_debug_read_scene_blas(IntPtr ctx, [Out] float[] nodes, [Out] int[] triIndex, [Out] int[] meshRoot);
+    [DllImport(Lib)] internal static extern int urt_debug_blas_cache_stats(IntPtr ctx, out ulong reused, out ulong built);
+    [DllImport(Lib)] internal static extern int urt_debug_serve_stats(IntPtr ctx, [Out] ulong[] out6);
     [DllImport(Lib)] internal static extern int urt_debug_build_walk_table(IntPtr heap, int nNodes, int nMeshes, int[] meshRoot, int[] smallFirst, float[] table, int capacityWords, out int words);
 
     // Unity's own API returns void and logs on error: the shim keeps that behaviour.

@@ -21,6 +21,14 @@ def test_header_and_binding_agree():
     assert header_symbols() == sorted(_lib.ABI_SYMBOLS)
 
 
+def test_csharp_binding_declares_every_entry_point():
+    """integration/UrtNative.cs is source only (no C# toolchain in this image): at least it must name every entry point of the header
+    in a [DllImport] declaration, and nothing the header does not have."""
+    text = open(os.path.join(ROOT, "integration", "UrtNative.cs")).read()
+    declared = set(re.findall(r"\[DllImport\(Lib\)\]\s+internal static extern [\w\[\]]+ (urt_\w+)\(", text))
+    assert declared == set(header_symbols()), (sorted(set(header_symbols()) - declared), sorted(declared - set(header_symbols())))
+
+
 def test_library_exports_every_declared_symbol(built_library):
     lib = C.CDLL(built_library)
     for name in header_symbols():
