@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--frames-per-launch", type=int, default=None, help="library option frames_per_launch (0 auto, 1 = one launch per frame, 2..64)")
     ap.add_argument("--gather-every", type=int, default=1, help="multi-GPU: gather the accumulated strips to rank 0 after every K-th frame (and after the last); "
                     "1 = the frame-end gather of every frame (default); a gather overwrites the whole image, so K > 1 only lowers the rate at which rank 0 could present it")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="urt_set_option NAME VALUE before the run (A/B of library options with the bench's own metric; reported in config.options)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--clock-warmup-ms", type=float, default=60.0,
                     help="before the W warm-up steps: run the same step untimed for this long so that the GPU has left its idle clocks "
@@ -140,6 +141,9 @@ def main():
         ctx.set_option("frames_per_launch", args.frames_per_launch)
     if args.kernel_mode is not None:
         ctx.set_option("kernel_mode", args.kernel_mode)
+    for kv in args.opt:
+        k, v = kv.split("=", 1)
+        ctx.set_option(k, int(v))
     ctx.set_option("time_dispatch", 1)
     master = RayTraceMaster(ctx, scene, rank=rank, world_size=world)
 
@@ -391,7 +395,7 @@ def main():
                        "frame": [width, height], "pixels_per_gpu": width * height // world,
                        "partition": (f"8-row strips round-robin over ranks, one gather per frame; {burst} frames per launch, each burst's gathers" + (" overlap the next burst's rendering" if overlap else " serialised")) if world > 1 else "single GPU",
                        "rays_per_step": int(total_rays / args.steps), "kernel_mode": args.kernel_mode if args.kernel_mode is not None else 3,
-                       **({"gather_every": args.gather_every} if world > 1 else {})},
+                       **({"gather_every": args.gather_every} if world > 1 else {}), **({"options": args.opt} if args.opt else {})},
             "roofline": roofline, "issue": issue, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

@@ -182,7 +182,7 @@ typedef struct urt_counters {
  *                             posted to a mailbox, any wave claims and walks them; "serve_refill" 1..64, "blas_min" up to 256):
  *                             measured alternative, slower than 3),
  *          "block_threads" (64 | 128 | 256: modes 0-2), "xcd_run" (0 = auto: 1..8 by launch size | >= 1: consecutive tiles a work-counter shard hands out as one run), "work_shards" (1 | 2 | ... | 64: work counters in use), "frame_group" (1..64: frames of a batched launch whose tile runs are interleaved; default 64 = all),
- *          "tile_order" (0 bottom-up | 1 top-down, the default: a launch ends with the rows nearest the ground plane), "waves_per_cu" (0 = auto, 1..32), "refill_min" (1..64),
+ *          "tile_order" (0 bottom-up | 1 top-down: a launch ends with the rows nearest the ground plane | -1 auto, the default: top-down for scenes without triangle meshes), "waves_per_cu" (0 = auto, 1..32), "refill_min" (1..64),
  *          mode 3: "blas_min" / "blas_exit" (0 = auto by scene | 1..64) / "shade_min" / "sky_min" (1..64): vote thresholds, "shade_split" (-1 auto | 0 | 1: surface hits and
  *                  sky misses as separate phases), "sched_block" (0 auto | 64 | 256),
  *                  "top_nodes" (0..256 triangle-BVH nodes kept in LDS), "top_front" (-1 auto | 0 | 1: where that top is

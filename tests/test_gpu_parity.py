@@ -83,13 +83,13 @@ SCHED_VARIANTS = [
     {"sched_block": 64, "top_nodes": 16, "top_front": 1},
     {"sched_block": 256, "top_nodes": 64, "top_front": 0, "lds_tlas": 0},
     {"sched_block": 256, "top_nodes": 256, "top_front": 1},
-    {"sched_block": 0, "top_nodes": 64, "top_front": -1, "tile_order": 0, "xcd_run": 5},
+    {"sched_block": 0, "top_nodes": 64, "top_front": -1, "tile_order": 1, "xcd_run": 5},
     {"refill_min": 1, "blas_min": 1, "blas_exit": 1, "shade_min": 1, "waves_per_cu": 3},
     {"refill_min": 64, "blas_min": 64, "blas_exit": 64, "shade_min": 64, "waves_per_cu": 32},
     {"front_list": 2},                                        # the listed FRONT (the default for this scene is the masked one)
     {"front_list": 0},                                        # neither: the heap walk with the BVH top inside it
 ]
-SCHED_DEFAULTS = {"sched_block": 0, "top_nodes": 64, "top_front": -1, "lds_tlas": 1, "tile_order": 1, "xcd_run": 0,
+SCHED_DEFAULTS = {"sched_block": 0, "top_nodes": 64, "top_front": -1, "lds_tlas": 1, "tile_order": -1, "xcd_run": 0,
                   "refill_min": 16, "blas_min": 0, "blas_exit": 0, "waves_per_cu": 0, "shade_min": 32, "front_list": -1}
 
 

@@ -141,9 +141,10 @@ struct urt_context {
   int opt_serve_refill = 16;                // kernel_mode 5: idle lanes of the traversal service that trigger a claim of waiting rays
   int opt_front_list = -1;                  // kernel_mode 3: listed FRONT for scenes of <= 12 MeshObjects (-1 auto = on, 0 off)
   int opt_shade_split = -1;                 // kernel_mode 3: -1 = auto (= split: measured better or equal on C2-C5), 0 = surface hits and misses shaded in one trip
-  int opt_tile_order = 1;                   // persistent modes: order in which the frame's tiles are handed out.  1 = top strip first: a launch then ENDS with the bottom
-                                            // rows, which in a scene on a ground plane hold the short paths without traversal (measured: C2 -3.5 .. -9 %, C3 -1.5 .. -4 %, C3D / C4 / C5 +-0.3 %,
-                                            // profiles/r03_logs/r3_probe_tile_order.log); any order draws the same pixels
+  int opt_tile_order = -1;                  // persistent modes: order in which the frame's tiles are handed out: 0 bottom strip first, 1 top strip first (a launch then ENDS with the
+                                            // bottom rows), -1 = auto: top first for scenes without triangle meshes (C2: -3.6 % in bench.py, -9 .. -12 % for launches of 1 - 20 frames),
+                                            // bottom first otherwise (C3, driver's 20-frame launch: top first +1.5 %; 64-frame launches, C3D, C4, C5: +-0.4 %) —
+                                            // profiles/r03_logs/r3_probe_tile_order.log; any order draws the same pixels
   int opt_lds_tlas = 1;                     // kernel_mode 3: object-level heaps, roots and spheres in LDS when small
   int opt_top_front = -1;                   // kernel_mode 3: top-of-forest walk inside the object-level phase (-1 = when the scene has several meshes)
   int opt_top_nodes = 64;                   // kernel_mode 3: triangle-BVH nodes kept in LDS (0 = none)
@@ -1013,7 +1014,7 @@ int do_dispatch(urt_context* ctx, int kernel, int gx, int gy, int gz, int first_
   P.first_group_row = first_row; P.row_stride = row_stride;
   P.n_strips = first_row < group_rows ? (group_rows - first_row + row_stride - 1) / row_stride : 0;
   P.tlas_stack = ctx->tlas_stack; P.blas_stack = ctx->blas_stack + ctx->opt_stack_pad; P.watchdog_steps = ctx->watchdog_steps;
-  P.block_threads = ctx->opt_block_threads; P.xcd_run = ctx->opt_xcd_run; P.tile_order = ctx->opt_tile_order; P.refill_min = ctx->opt_refill_min;
+  P.block_threads = ctx->opt_block_threads; P.xcd_run = ctx->opt_xcd_run; P.tile_order = ctx->opt_tile_order >= 0 ? ctx->opt_tile_order : (S.n_meshes == 0 ? 1 : 0); P.refill_min = ctx->opt_refill_min;
   // lanes parked at a triangle BVH before the traversal phase runs: 16 with one mesh (C3 -2 %, C3D -6 % against 28), 24 when rays walk
   // several (C4, C5 -1 %) — re-measured after the work distribution became local (profiles/r02_logs/r2_blas_min.log)
   P.blas_min = ctx->opt_blas_min > 0 ? ctx->opt_blas_min : (S.n_meshes > 1 ? 24 : 16);
@@ -1622,7 +1623,7 @@ int urt_set_option(urt_context* ctx, const char* name, int value) {
     if (value < 1 || value > 64) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "sky_min must be in [1, 64]");
     ctx->opt_sky_min = value;
   } else if (std::strcmp(name, "tile_order") == 0) {
-    if (value < 0 || value > 1) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "tile_order must be 0 or 1");
+    if (value < -1 || value > 1) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "tile_order must be -1 (auto), 0 or 1");
     ctx->opt_tile_order = value;
   } else if (std::strcmp(name, "lds_tlas") == 0) {
     ctx->opt_lds_tlas = value ? 1 : 0;
