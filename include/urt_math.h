@@ -257,6 +257,44 @@ URT_HD float blas_rcp(float d) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Slab test of the triangle BVH on CENTRE / HALF-EXTENT boxes (not a reference function: the reference has no triangle BVH).
+// The builders and the refit produce [lo, hi] child boxes; the traversal reads a derived copy in which every box is (c, h) with
+// [c - h, c + h] containing [lo, hi] (box_center_form: h rounded up).  Per axis
+//     t_mid = c / d - o / d = fma(c, idir, b),   dh = (h + pad) / |d| = fma(h, |idir|, pa),   t_near = t_mid - dh,  t_far = t_mid + dh
+// so the near / far planes need no per-axis min / max (half-rate instructions on gfx950, profiles/r03_logs/r3_valu_table_microbench.log):
+// twelve add / sub instead of twelve min / max per node step, same [0, best t] clamp.  pad = 2^-16 max|origin| widens every box per ray on top
+// of the build-time pad (2^-16 of the mesh extent), which together cover the rounding of these few operations (2^-22 (|o| + |c| + h) / |d|)
+// and of the Moller-Trumbore test by a factor of 64 — as the [lo, hi] form did.  Shared by the kernels and the oracle's culled mode.
+// ---------------------------------------------------------------------------------------------
+struct CRay { v3 idir, b, pa; };        // 1/d (blas_rcp), -(o / d), pad / |d|
+URT_HD CRay cray(v3 o, v3 d) {
+  CRay R;
+  float pad = f_max(f_max(f_abs(o.x), f_abs(o.y)), f_abs(o.z)) * 1.52587890625e-5f;
+  R.idir = mk3(blas_rcp(d.x), blas_rcp(d.y), blas_rcp(d.z));
+  R.b = mk3(-(o.x * R.idir.x), -(o.y * R.idir.y), -(o.z * R.idir.z));
+  R.pa = mk3(pad * f_abs(R.idir.x), pad * f_abs(R.idir.y), pad * f_abs(R.idir.z));
+  return R;
+}
+// [lo, hi] -> (c, h); an inverted (empty) box becomes one no ray enters
+URT_HD void box_center_form(const float lo[3], const float hi[3], float c[3], float h[3]) {
+  bool empty = false;
+  for (int a = 0; a < 3; a++) empty = empty || !(lo[a] <= hi[a]);
+  for (int a = 0; a < 3; a++) {
+    float m = 0.5f * lo[a] + 0.5f * hi[a];
+    float r = f_max(m - lo[a], hi[a] - m) * 1.0000005f + 1e-37f;
+    c[a] = empty ? 0.0f : m;
+    h[a] = empty ? -3.0e38f : r;
+  }
+}
+// t_near (clamped to 0) and t_far (clamped to tbest) of one box; the box is entered iff tn <= tf
+URT_HD void cslab(float cx, float cy, float cz, float hx, float hy, float hz, const CRay& R, float tbest, float& tn, float& tf) {
+  float mx = f_fma(cx, R.idir.x, R.b.x), my = f_fma(cy, R.idir.y, R.b.y), mz = f_fma(cz, R.idir.z, R.b.z);
+  float dx = f_fma(hx, f_abs(R.idir.x), R.pa.x), dy = f_fma(hy, f_abs(R.idir.y), R.pa.y), dz = f_fma(hz, f_abs(R.idir.z), R.pa.z);
+  tn = f_max(f_max(f_max(mx - dx, my - dy), mz - dz), 0.0f);
+  tf = f_min(f_min(f_min(mx + dx, my + dy), mz + dz), tbest);
+}
+
+// ---------------------------------------------------------------------------------------------
 // rand()  (RS:77-81, A.1).  State: pixel (float2 of absolute pixel coordinates) + running seed.
 // ---------------------------------------------------------------------------------------------
 // x / c for a CONSTANT c whose correctly rounded reciprocal is y, without the divider: q = RN(x y), r = x - q c (exact, one

@@ -239,16 +239,13 @@ struct Tracer {
   // mode 1: enumerate candidate triangles through the BVH.  Node = 16 floats:
   // c0.min c0.max c1.min c1.max (12 floats), child0, child1 (int bits), 2 pad.  child >= 0 interior
   // node index; child < 0 leaf, code = ~child, first leaf-order slot = code >> 3, count = (code & 7) + 1.
-  // Root 0x7fffffff = empty mesh.  The slab test is the product's (DESIGN.md "BLAS traversal"): boxes
-  // widened per ray by pad = 2^-16 * max|origin| (on top of the pad baked in at build time), culled
+  // Root 0x7fffffff = empty mesh.  The slab test is the product's (include/urt_math.h "Slab test of the triangle BVH ..."): boxes as
+  // (centre, half extent), widened per ray by pad = 2^-16 * max|origin| (on top of the pad baked in at build time), culled
   // against [0, best t] inclusive; both children hit => nearer first (ties: child0).
   void TraverseBlas(const Ray& ray, RayHit& bestHit, const urt_MeshObject& mo, int32_t root, int& best_i) {
     if (root == 0x7fffffff) return;
     v3 o = ray.origin, d = ray.direction;
-    float pad = f_max(f_max(f_abs(o.x), f_abs(o.y)), f_abs(o.z)) * 1.52587890625e-5f;
-    v3 idir = mk3(blas_rcp(d.x), blas_rcp(d.y), blas_rcp(d.z));
-    v3 nop = mk3(-((o.x + pad) * idir.x), -((o.y + pad) * idir.y), -((o.z + pad) * idir.z));
-    v3 nom = mk3(-((o.x - pad) * idir.x), -((o.y - pad) * idir.y), -((o.z - pad) * idir.z));
+    const CRay R = cray(o, d);
     int32_t stack[128];
     int sp = 0;
     int32_t cur = root;
@@ -259,13 +256,11 @@ struct Tracer {
         float tb = bestHit.distance;
         float tn[2]; bool h[2];
         for (int c = 0; c < 2; c++) {
-          const float* b = n + 6 * c;
-          float t1x = f_fma(b[0], idir.x, nop.x), t2x = f_fma(b[3], idir.x, nom.x);
-          float t1y = f_fma(b[1], idir.y, nop.y), t2y = f_fma(b[4], idir.y, nom.y);
-          float t1z = f_fma(b[2], idir.z, nop.z), t2z = f_fma(b[5], idir.z, nom.z);
-          float tnear = f_max(f_max(f_min(t1x, t2x), f_min(t1y, t2y)), f_max(f_min(t1z, t2z), 0.0f));
-          float tfar = f_min(f_min(f_max(t1x, t2x), f_max(t1y, t2y)), f_min(f_max(t1z, t2z), tb));
-          tn[c] = tnear; h[c] = tnear <= tfar;
+          // the product's traversal reads (centre, half extent) boxes derived from these [lo, hi] boxes: the same derivation, the same slab arithmetic
+          float cc[3], hh[3], tf;
+          box_center_form(n + 6 * c, n + 6 * c + 3, cc, hh);
+          cslab(cc[0], cc[1], cc[2], hh[0], hh[1], hh[2], R, tb, tn[c], tf);
+          h[c] = tn[c] <= tf;
         }
         int32_t c0 = (int32_t)f_bits(n[12]), c1 = (int32_t)f_bits(n[13]);
         if (h[0] && h[1]) {

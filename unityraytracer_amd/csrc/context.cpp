@@ -92,6 +92,7 @@ struct urt_context {
   int opt_refit = 1;                        // 0 = always prepare from scratch
   int opt_qnodes = 0;                       // 32-byte quantized nodes in the traversal loop: 0 = off (default: measured -1.3 % on C3 / C3D, +1.3 % on C4 / C5 — the loop waits on the latency of ONE dependent fetch per step, not on its width), 1 = on, -1 = on unless a MeshObject is only a few grid cells wide
   float4* qbuf = nullptr;                   // frame + quantized nodes of the prepared scene (in scene_allocs)
+  float4* cbuf = nullptr;                   // centre / half-extent copy of the nodes of the prepared scene (in scene_allocs): DevScene::blas_cnodes
   float qnode_quality = 0;                  // smallest MeshObject extent in grid cells (csrc/qnodes.hip)
   std::vector<uint8_t> prev_mesh_objects;   // the _MeshObjects records of the prepared scene
   std::vector<int32_t> h_mesh_root, h_small_first;
@@ -236,7 +237,7 @@ void free_scene(urt_context* ctx) {
   ctx->scene_allocs.clear();
   ctx->ds = DevScene{};
   ctx->refit = urt_context::RefitAux{};
-  ctx->qbuf = nullptr;
+  ctx->qbuf = nullptr; ctx->cbuf = nullptr;
   ctx->cap_materials = ctx->cap_mesh_tlas = ctx->cap_sphere_tlas = ctx->cap_sphere_pr = 0;
 }
 
@@ -377,6 +378,18 @@ void pack_tlas(const Buffer* b, std::vector<float>& out) {
   }
 }
 
+int requantize(urt_context* ctx);
+// (Re)derive what the trace kernels read from the [lo, hi] nodes of the prepared scene — after a build and after every refit: the
+// centre / half-extent copy (always) and the quantized copy (option qnodes).
+int rederive_nodes(urt_context* ctx) {
+  DevScene& S = ctx->ds;
+  S.blas_cnodes = nullptr;
+  if (ctx->cbuf && ctx->n_blas_nodes > 0) {
+    URT_HIP(ctx, center_nodes(S.blas_nodes, ctx->n_blas_nodes, ctx->cbuf, ctx->stream));
+    S.blas_cnodes = ctx->cbuf;
+  }
+  return requantize(ctx);
+}
 // (Re)derive the quantized nodes from the float nodes of the prepared scene and decide whether the traversal loop uses them.
 int requantize(urt_context* ctx) {
   DevScene& S = ctx->ds;
@@ -486,7 +499,7 @@ int prepare_incremental(urt_context* ctx) {
                              ctx->refit.vertices, ctx->refit.indices, ctx->refit.depth, std::max(0, ctx->scene_max_depth - 1), ctx->refit.node_mesh,
                              ctx->refit.matrices, ctx->refit.moved, ctx->refit.ext, n_meshes, ctx->refit.cbox, ctx->stream));
     ctx->refitted_meshes += (uint64_t)n_moved;
-    if ((rc = requantize(ctx))) return rc;
+    if ((rc = rederive_nodes(ctx))) return rc;
   }
   ctx->prev_mesh_objects.assign(bm ? bm->host.begin() : ctx->prev_mesh_objects.begin(), bm ? bm->host.begin() + (ptrdiff_t)((size_t)n_meshes * URT_STRIDE_MESHOBJECT) : ctx->prev_mesh_objects.begin());
   ctx->scene_dirty = false; ctx->dirty_slots = 0; ctx->dirty_full = false;
@@ -647,13 +660,19 @@ int prepare_scene(urt_context* ctx) {
   ctx->watchdog_steps = (unsigned int)std::min<size_t>(0x7fffffffu, 8 * (n_blas_nodes + n_tris) + 4096);
   if ((size_t)(ctx->tlas_stack + ctx->blas_stack) * 64 * 4 * sizeof(int) > 150 * 1024)   // 4-wave workgroup; a CU has 160 KiB
     return fail(ctx, URT_ERR_SCENE, "traversal stacks exceed the LDS of a compute unit");
+  if (n_blas_nodes > 0) {                                     // the copy of the nodes the trace kernels traverse: child boxes as (centre, half extent)
+    void* c = nullptr;
+    URT_HIP(ctx, hipMalloc(&c, 4 * n_blas_nodes * sizeof(float4)));
+    ctx->scene_allocs.push_back(c);
+    ctx->cbuf = (float4*)c;
+  }
   if (ctx->opt_qnodes != 0 && n_blas_nodes > 0) {             // 32-byte quantized nodes for the traversal loop (csrc/qnodes.hip)
     void* q = nullptr;
     URT_HIP(ctx, hipMalloc(&q, (2 + 2 * n_blas_nodes) * sizeof(float4)));
     ctx->scene_allocs.push_back(q);
     ctx->qbuf = (float4*)q;
-    if ((rc = requantize(ctx))) return rc;
   }
+  if ((rc = rederive_nodes(ctx))) return rc;
   // what a later in-place update needs (prepare_incremental): the records this scene was prepared from, and — when it has triangle
   // BVHs — device copies of _Vertices / _Indices plus every node's parent and MeshObject (csrc/refit.hip)
   ctx->prev_mesh_objects.assign(bm ? bm->host.begin() : ctx->prev_mesh_objects.end(), bm ? bm->host.begin() + (ptrdiff_t)((size_t)n_meshes * URT_STRIDE_MESHOBJECT) : ctx->prev_mesh_objects.end());

@@ -145,16 +145,15 @@ __device__ __forceinline__ void test_leaf(const DevScene& S, int32_t leaf, v3 o,
 // ---------------------------------------------------------------------------------------------------
 static constexpr int32_t kBlasDone = (int32_t)0x80000000;   // never a valid leaf code (it would be ~0x7fffffff)
 
-struct BlasRay { v3 idir, nop, nom; };   // per-ray slab constants: t = fma(bound, idir, nop|nom)
-
-// boxes are widened per ray by pad = 2^-16 * max|origin| on top of the build-time pad (DESIGN.md "BLAS traversal")
-__device__ __forceinline__ BlasRay blas_ray(v3 o, v3 d) {
-  BlasRay R;
-  float pad = f_max(f_max(f_abs(o.x), f_abs(o.y)), f_abs(o.z)) * 1.52587890625e-5f;
-  R.idir = mk3(blas_rcp(d.x), blas_rcp(d.y), blas_rcp(d.z));
-  R.nop = mk3(-((o.x + pad) * R.idir.x), -((o.y + pad) * R.idir.y), -((o.z + pad) * R.idir.z));
-  R.nom = mk3(-((o.x - pad) * R.idir.x), -((o.y - pad) * R.idir.y), -((o.z - pad) * R.idir.z));
-  return R;
+// per-ray constants of the slab test on centre / half-extent boxes (include/urt_math.h "Slab test of the triangle BVH ..."): the
+// traversal reads S.blas_cnodes, the (c, h) copy of the builders' [lo, hi] nodes —
+//   q0 = c0.xyz, h0.x   q1 = h0.yz, c1.xy   q2 = c1.z, h1.xyz   q3 = child0, child1 (int bits), 0, 0
+using BlasRay = CRay;
+__device__ __forceinline__ BlasRay blas_ray(v3 o, v3 d) { return cray(o, d); }
+// both children's [t near, t far]
+__device__ __forceinline__ void cnode_slabs(float4 q0, float4 q1, float4 q2, const BlasRay& R, float tbest, float& tn0, float& tf0, float& tn1, float& tf1) {
+  cslab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, R, tbest, tn0, tf0);
+  cslab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, R, tbest, tn1, tf1);
 }
 
 __device__ __forceinline__ int32_t blas_pop(int* stk, int& sp) {
@@ -166,18 +165,8 @@ __device__ __forceinline__ int32_t blas_pop(int* stk, int& sp) {
 // One interior-node step: slab-test both children against [0, tbest], descend into the nearer hit child (ties: child 0),
 // push the other; returns the next cursor.
 __device__ __forceinline__ int32_t blas_node_eval(float4 q0, float4 q1, float4 q2, float4 q3, const BlasRay& R, float tbest, int* stk, int& sp) {
-  // child 0: min (q0.x q0.y q0.z) max (q0.w q1.x q1.y)
-  float a1x = f_fma(q0.x, R.idir.x, R.nop.x), a2x = f_fma(q0.w, R.idir.x, R.nom.x);
-  float a1y = f_fma(q0.y, R.idir.y, R.nop.y), a2y = f_fma(q1.x, R.idir.y, R.nom.y);
-  float a1z = f_fma(q0.z, R.idir.z, R.nop.z), a2z = f_fma(q1.y, R.idir.z, R.nom.z);
-  float tn0 = f_max(f_max(f_min(a1x, a2x), f_min(a1y, a2y)), f_max(f_min(a1z, a2z), 0.0f));
-  float tf0 = f_min(f_min(f_max(a1x, a2x), f_max(a1y, a2y)), f_min(f_max(a1z, a2z), tbest));
-  // child 1: min (q1.z q1.w q2.x) max (q2.y q2.z q2.w)
-  float b1x = f_fma(q1.z, R.idir.x, R.nop.x), b2x = f_fma(q2.y, R.idir.x, R.nom.x);
-  float b1y = f_fma(q1.w, R.idir.y, R.nop.y), b2y = f_fma(q2.z, R.idir.y, R.nom.y);
-  float b1z = f_fma(q2.x, R.idir.z, R.nop.z), b2z = f_fma(q2.w, R.idir.z, R.nom.z);
-  float tn1 = f_max(f_max(f_min(b1x, b2x), f_min(b1y, b2y)), f_max(f_min(b1z, b2z), 0.0f));
-  float tf1 = f_min(f_min(f_max(b1x, b2x), f_max(b1y, b2y)), f_min(f_max(b1z, b2z), tbest));
+  float tn0, tf0, tn1, tf1;
+  cnode_slabs(q0, q1, q2, R, tbest, tn0, tf0, tn1, tf1);
   bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
   int32_t c0 = as_int(q3.x), c1 = as_int(q3.y);
   if (h0 && h1) {
@@ -197,16 +186,8 @@ __device__ __forceinline__ int32_t blas_node_eval(float4 q0, float4 q1, float4 q
 // sp <= depth of the tree always exists: the stack has depth + 1 entries), and cursor / height are selected.
 __device__ __forceinline__ int32_t blas_node_eval_flat(float4 q0, float4 q1, float4 q2, float4 q3, const BlasRay& R, float tbest, int* stk, int& sp) {
   int below = stk[max(sp - 1, 0) * 64];
-  float a1x = f_fma(q0.x, R.idir.x, R.nop.x), a2x = f_fma(q0.w, R.idir.x, R.nom.x);
-  float a1y = f_fma(q0.y, R.idir.y, R.nop.y), a2y = f_fma(q1.x, R.idir.y, R.nom.y);
-  float a1z = f_fma(q0.z, R.idir.z, R.nop.z), a2z = f_fma(q1.y, R.idir.z, R.nom.z);
-  float tn0 = f_max(f_max(f_min(a1x, a2x), f_min(a1y, a2y)), f_max(f_min(a1z, a2z), 0.0f));
-  float tf0 = f_min(f_min(f_max(a1x, a2x), f_max(a1y, a2y)), f_min(f_max(a1z, a2z), tbest));
-  float b1x = f_fma(q1.z, R.idir.x, R.nop.x), b2x = f_fma(q2.y, R.idir.x, R.nom.x);
-  float b1y = f_fma(q1.w, R.idir.y, R.nop.y), b2y = f_fma(q2.z, R.idir.y, R.nom.y);
-  float b1z = f_fma(q2.x, R.idir.z, R.nop.z), b2z = f_fma(q2.w, R.idir.z, R.nom.z);
-  float tn1 = f_max(f_max(f_min(b1x, b2x), f_min(b1y, b2y)), f_max(f_min(b1z, b2z), 0.0f));
-  float tf1 = f_min(f_min(f_max(b1x, b2x), f_max(b1y, b2y)), f_min(f_max(b1z, b2z), tbest));
+  float tn0, tf0, tn1, tf1;
+  cnode_slabs(q0, q1, q2, R, tbest, tn0, tf0, tn1, tf1);
   bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
   int32_t c0 = as_int(q3.x), c1 = as_int(q3.y);
   bool both = h0 && h1, none = !h0 && !h1;
@@ -232,32 +213,29 @@ __device__ __forceinline__ int32_t blas_node_select_ptr(bool h0, bool h1, float 
 }
 __device__ __forceinline__ int32_t blas_node_eval_ptr(float4 q0, float4 q1, float4 q2, float4 q3, const BlasRay& R, float tbest, int*& top_) {
   int32_t below = *top_;
-  float a1x = f_fma(q0.x, R.idir.x, R.nop.x), a2x = f_fma(q0.w, R.idir.x, R.nom.x);
-  float a1y = f_fma(q0.y, R.idir.y, R.nop.y), a2y = f_fma(q1.x, R.idir.y, R.nom.y);
-  float a1z = f_fma(q0.z, R.idir.z, R.nop.z), a2z = f_fma(q1.y, R.idir.z, R.nom.z);
-  float tn0 = f_max(f_max(f_min(a1x, a2x), f_min(a1y, a2y)), f_max(f_min(a1z, a2z), 0.0f));
-  float tf0 = f_min(f_min(f_max(a1x, a2x), f_max(a1y, a2y)), f_min(f_max(a1z, a2z), tbest));
-  float b1x = f_fma(q1.z, R.idir.x, R.nop.x), b2x = f_fma(q2.y, R.idir.x, R.nom.x);
-  float b1y = f_fma(q1.w, R.idir.y, R.nop.y), b2y = f_fma(q2.z, R.idir.y, R.nom.y);
-  float b1z = f_fma(q2.x, R.idir.z, R.nop.z), b2z = f_fma(q2.w, R.idir.z, R.nom.z);
-  float tn1 = f_max(f_max(f_min(b1x, b2x), f_min(b1y, b2y)), f_max(f_min(b1z, b2z), 0.0f));
-  float tf1 = f_min(f_min(f_max(b1x, b2x), f_max(b1y, b2y)), f_min(f_max(b1z, b2z), tbest));
+  float tn0, tf0, tn1, tf1;
+  cnode_slabs(q0, q1, q2, R, tbest, tn0, tf0, tn1, tf1);
   return blas_node_select_ptr(tn0 <= tf0, tn1 <= tf1, tn0, tn1, as_int(q3.x), as_int(q3.y), below, top_);
 }
 
 // The same step on a 32-byte QUANTIZED node (csrc/qnodes.hip): two dwordx4 loads instead of four.  The twelve planes are 16-bit grid
 // coordinates q; a plane's slab value is t = (origin + q cell - (o +- pad)) / d = fma(Q, S, B) with Q = 2^23 + q — built in ONE
 // instruction per plane by putting q into the mantissa of 2^23 (0x4B000000 | q) —, S = cell / d and B = (origin - (o +- pad)) / d - 2^23 S
-// per axis (QRay, derived from the BlasRay at phase entry).  The 2^23 S terms cancel exactly but for the rounding of B: half a cell
+// per axis (QRay, derived from the ray at phase entry).  The 2^23 S terms cancel exactly but for the rounding of B: half a cell
 // at worst, covered by the two cells the quantizer adds on every side.  Conservative culling only: the hits are the triangle tests'.
 struct QRay { v3 S, Bp, Bm; };
-__device__ __forceinline__ QRay make_qray(const BlasRay& R, float4 forg, float4 fcell) {
+__device__ __forceinline__ QRay make_qray(v3 o, v3 d, float4 forg, float4 fcell) {
+  // the quantized planes are [lo, hi] planes: their per-ray constants are -(o +- pad) / d
+  const float pad = f_max(f_max(f_abs(o.x), f_abs(o.y)), f_abs(o.z)) * 1.52587890625e-5f;
+  const v3 idir = mk3(blas_rcp(d.x), blas_rcp(d.y), blas_rcp(d.z));
+  const v3 nop = mk3(-((o.x + pad) * idir.x), -((o.y + pad) * idir.y), -((o.z + pad) * idir.z));
+  const v3 nom = mk3(-((o.x - pad) * idir.x), -((o.y - pad) * idir.y), -((o.z - pad) * idir.z));
   QRay Q;
-  Q.S = mk3(fcell.x * R.idir.x, fcell.y * R.idir.y, fcell.z * R.idir.z);
-  Q.Bp = mk3(f_fma(-8388608.0f, Q.S.x, f_fma(forg.x, R.idir.x, R.nop.x)), f_fma(-8388608.0f, Q.S.y, f_fma(forg.y, R.idir.y, R.nop.y)),
-             f_fma(-8388608.0f, Q.S.z, f_fma(forg.z, R.idir.z, R.nop.z)));
-  Q.Bm = mk3(f_fma(-8388608.0f, Q.S.x, f_fma(forg.x, R.idir.x, R.nom.x)), f_fma(-8388608.0f, Q.S.y, f_fma(forg.y, R.idir.y, R.nom.y)),
-             f_fma(-8388608.0f, Q.S.z, f_fma(forg.z, R.idir.z, R.nom.z)));
+  Q.S = mk3(fcell.x * idir.x, fcell.y * idir.y, fcell.z * idir.z);
+  Q.Bp = mk3(f_fma(-8388608.0f, Q.S.x, f_fma(forg.x, idir.x, nop.x)), f_fma(-8388608.0f, Q.S.y, f_fma(forg.y, idir.y, nop.y)),
+             f_fma(-8388608.0f, Q.S.z, f_fma(forg.z, idir.z, nop.z)));
+  Q.Bm = mk3(f_fma(-8388608.0f, Q.S.x, f_fma(forg.x, idir.x, nom.x)), f_fma(-8388608.0f, Q.S.y, f_fma(forg.y, idir.y, nom.y)),
+             f_fma(-8388608.0f, Q.S.z, f_fma(forg.z, idir.z, nom.z)));
   return Q;
 }
 __device__ __forceinline__ float q_lo16(float w) { return as_float((int)(((unsigned int)as_int(w) & 0xffffu) | 0x4B000000u)); }
@@ -285,7 +263,7 @@ __device__ __forceinline__ int32_t blas_node_step(const DevScene& S, int32_t cur
                                                   LocalCounters& lc) {
   if (COUNT) lc.blas_nodes++;
   // uniform base + 32-bit byte offset (the node array is < 4 GiB: checked on the host), so the load needs no 64-bit address math
-  const float4* n = (const float4*)((const char*)S.blas_nodes + ((uint32_t)cur << 6));
+  const float4* n = (const float4*)((const char*)S.blas_cnodes + ((uint32_t)cur << 6));
   float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
   return blas_node_eval(q0, q1, q2, q3, R, tbest, stk, sp);
 }
@@ -1226,7 +1204,7 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
   extern __shared__ int lds[];
   float4* lds4 = (float4*)lds;
   const float4* top = lds4;
-  for (int i = threadIdx.x; i < P.top_nodes * 4; i += blockDim.x) lds4[i] = S.blas_nodes[i];
+  for (int i = threadIdx.x; i < P.top_nodes * 4; i += blockDim.x) lds4[i] = S.blas_cnodes[i];
   int at = P.top_nodes * 4;                                     // running offset in float4 units
   FrontLds L;
   if (P.lds_mesh) {                                             // object-level mesh heap + MeshObject roots
@@ -1416,7 +1394,7 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
       int budget = __builtin_amdgcn_readfirstlane((int)min(P.watchdog_steps, 0x7fffffffu));   // trips left before the watchdog ends this phase (counted down: no kernel argument in the loop)
       const int exit_s = __builtin_amdgcn_readfirstlane(exit_below);
       QRay Q;
-      if (QN) Q = make_qray(R, S.blas_qnodes[0], S.blas_qnodes[1]);     // the grid frame: two wave-uniform loads per phase entry
+      if (QN) Q = make_qray(o, d, S.blas_qnodes[0], S.blas_qnodes[1]);     // the grid frame: two wave-uniform loads per phase entry
 #ifdef URT_MINORITY
       int starve = 0;
 #endif
@@ -1455,10 +1433,10 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
             }
           } else if (c >= 0) {
             if (COUNT) lc.blas_nodes++;
-            const float4* n = (const float4*)((const char*)S.blas_nodes + ((uint32_t)c << 6));
+            const float4* n = (const float4*)((const char*)S.blas_cnodes + ((uint32_t)c << 6));
             float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
 #ifdef URT_EXTRA_NODE_LOADS                // A/B probe: how sensitive is the loop to vector-memory instructions per node step?
-            { const float4* n2 = (const float4*)((const char*)S.blas_nodes + ((uint32_t)(c > 0 ? c - 1 : c + 1) << 6)); float4 x0 = n2[0], x1 = n2[1]; asm volatile("" :: "v"(x0.x), "v"(x1.x)); }
+            { const float4* n2 = (const float4*)((const char*)S.blas_cnodes + ((uint32_t)(c > 0 ? c - 1 : c + 1) << 6)); float4 x0 = n2[0], x1 = n2[1]; asm volatile("" :: "v"(x0.x), "v"(x1.x)); }
 #endif
             c = blas_node_eval_ptr(q0, q1, q2, q3, R, best.t, spp);
           }
@@ -1583,7 +1561,7 @@ __global__ __launch_bounds__(BLOCK, URT_SERVE_OCC) void k_serve(DevScene S, Fram
   extern __shared__ int lds[];
   float4* lds4 = (float4*)lds;
   const float4* top = lds4;
-  for (int i = threadIdx.x; i < P.top_nodes * 4; i += blockDim.x) lds4[i] = S.blas_nodes[i];
+  for (int i = threadIdx.x; i < P.top_nodes * 4; i += blockDim.x) lds4[i] = S.blas_cnodes[i];
   int at = P.top_nodes * 4;                                     // running offset in float4 units
   FrontLds L;
   if (P.lds_mesh) {
@@ -1744,7 +1722,7 @@ __global__ __launch_bounds__(BLOCK, URT_SERVE_OCC) void k_serve(DevScene S, Fram
       const bool others = nS + nK + nF > 0 || can_refill;     // own work waits: yield once the loop runs thin
       bool factive = false;
       v3 fo = mk3(0, 0, 0), fd = mk3(0, 0, 1);
-      BlasRay R; R.idir = mk3(0, 0, 0); R.nop = mk3(0, 0, 0); R.nom = mk3(0, 0, 0);
+      BlasRay R; R.idir = mk3(0, 0, 0); R.b = mk3(0, 0, 0); R.pa = mk3(0, 0, 0);
       HitRec fb; fb.t = URT_INF; fb.kid = 0; fb.u = 0; fb.v = 0;
       int fbest_i = -1, fsp = 0, fhome = 0;
       int32_t fcur = kBlasDone;
@@ -1824,7 +1802,7 @@ __global__ __launch_bounds__(BLOCK, URT_SERVE_OCC) void k_serve(DevScene S, Fram
             if (COUNT) lc.blas_nodes++;
             float4 q0, q1, q2, q3;
             if (FMODE == 0 && fcur < P.top_nodes) { const float4* n = top + 4 * fcur; q0 = n[0]; q1 = n[1]; q2 = n[2]; q3 = n[3]; }
-            else { const float4* n = (const float4*)((const char*)S.blas_nodes + ((uint32_t)fcur << 6)); q0 = n[0]; q1 = n[1]; q2 = n[2]; q3 = n[3]; }
+            else { const float4* n = (const float4*)((const char*)S.blas_cnodes + ((uint32_t)fcur << 6)); q0 = n[0]; q1 = n[1]; q2 = n[2]; q3 = n[3]; }
             fcur = blas_node_eval(q0, q1, q2, q3, R, fb.t, fstk, fsp);
           }
         } else if (factive && !interior) {

@@ -1,4 +1,5 @@
-// qnodes.hip — 32-byte quantized copies of the triangle-BVH nodes for the traversal loop of the default trace kernel.
+// qnodes.hip — the traversal's derived copies of the triangle-BVH nodes: centre / half-extent boxes (k_center: what every trace kernel reads)
+// and, optionally, 32-byte quantized nodes for the traversal loop of the default trace kernel.
 //
 // Measured (profiles/r03_logs/r3_ab_vote_xload.log): the loop is sensitive to the number of vector-memory instructions per node
 // step — two extra dwordx4 loads per step cost +14..19 % frame time.  A 64-byte node (two child boxes as 12 floats + two child
@@ -109,9 +110,31 @@ __global__ __launch_bounds__(256) void k_quantize(const float4* __restrict__ nod
   qbuf[2 + 2 * (size_t)n + 1] = make_float4(as_f(w[4]), as_f(w[5]), q3.x, q3.y);
 }
 
+// The traversal's copy of the nodes: every child box as centre / half extent (include/urt_math.h box_center_form), child codes unchanged.
+//   q0 = c0.xyz, h0.x   q1 = h0.yz, c1.xy   q2 = c1.z, h1.xyz   q3 = child0, child1, 0, 0
+__global__ __launch_bounds__(256) void k_center(const float4* __restrict__ nodes, int n_nodes, float4* __restrict__ cnodes) {
+  int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= n_nodes) return;
+  float4 q0 = nodes[4 * (size_t)n], q1 = nodes[4 * (size_t)n + 1], q2 = nodes[4 * (size_t)n + 2], q3 = nodes[4 * (size_t)n + 3];
+  const float l0[3] = {q0.x, q0.y, q0.z}, h0[3] = {q0.w, q1.x, q1.y}, l1[3] = {q1.z, q1.w, q2.x}, h1[3] = {q2.y, q2.z, q2.w};
+  float c0[3], e0[3], c1[3], e1[3];
+  box_center_form(l0, h0, c0, e0);
+  box_center_form(l1, h1, c1, e1);
+  cnodes[4 * (size_t)n] = make_float4(c0[0], c0[1], c0[2], e0[0]);
+  cnodes[4 * (size_t)n + 1] = make_float4(e0[1], e0[2], c1[0], c1[1]);
+  cnodes[4 * (size_t)n + 2] = make_float4(c1[2], e1[0], e1[1], e1[2]);
+  cnodes[4 * (size_t)n + 3] = q3;
+}
+
 }  // namespace
 
 namespace urtd {
+
+hipError_t center_nodes(const float4* nodes, int n_nodes, float4* cnodes, hipStream_t st) {
+  if (n_nodes <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_center, dim3((n_nodes + 255) / 256), dim3(256), 0, st, nodes, n_nodes, cnodes);
+  return hipGetLastError();
+}
 
 hipError_t quantize_nodes(const float4* nodes, int n_nodes, const int32_t* mesh_root, int n_meshes, float4* qbuf, hipStream_t st) {
   if (n_nodes <= 0) return hipSuccess;

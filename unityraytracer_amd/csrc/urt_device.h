@@ -33,7 +33,8 @@ struct DevScene {
   // the phase scheduler keeps of them (in triangles), or -1; n_small = triangles in that copy (0 = none)
   const int32_t* mesh_small_first; int n_small;
   // triangle BVH over world-space triangles, all meshes in one pool
-  const float4* blas_nodes;  // 4 x float4 per node
+  const float4* blas_nodes;  // 4 x float4 per node: child boxes as [lo, hi] — what the builders and the refit write
+  const float4* blas_cnodes; // the same nodes with child boxes as (centre, half extent): what the trace kernels read (csrc/qnodes.hip k_center)
   const float4* blas_qnodes; // or null: [0] grid origin.xyz, quality  [1] cell.xyz, 0  [2 + 2n ..] the 32-byte quantized form of node n (csrc/qnodes.hip)
   const float4* tri_verts;   // [3k] v0.xyz, index slot i (int bits)  [3k+1] e1.xyz, mesh id (int bits)  [3k+2] e2.xyz, 0
   const float4* tri_norms;   // [3k..3k+2] n0, n1, n2 (object space, RS:259-261)
