@@ -185,12 +185,12 @@ typedef struct urt_counters {
  *          "tile_order" (0 bottom-up | 1 top-down: a launch ends with the rows nearest the ground plane | -1 auto, the default: top-down for scenes without triangle meshes), "waves_per_cu" (0 = auto, 1..32), "refill_min" (1..64),
  *          mode 3: "blas_min" / "blas_exit" (0 = auto by scene | 1..64) / "shade_min" / "sky_min" (1..64): vote thresholds, "shade_split" (-1 auto | 0 | 1: surface hits and
  *                  sky misses as separate phases), "sched_block" (0 auto | 64 | 256),
- *                  "top_nodes" (0..256 triangle-BVH nodes kept in LDS), "top_front" (-1 auto | 0 | 1: where that top is
+ *                  "top_nodes" (0..256 triangle-BVH nodes kept in LDS; -1 auto, the default: 64, or twice the number of big MeshObjects when the object-level phase is the masked one), "top_front" (-1 auto | 0 | 1: where that top is
  *                  walked), "front_list" (-1 auto | 0 | 1 | 2: multi-mesh scenes determine the objects a ray must test first and work them off in voted
  *                  trips — auto / 1: by mask arithmetic over the heap when it has <= 31 nodes, else as a list when <= 12 MeshObjects; 2: always the list), "lds_tlas" (0/1: small object-level tables in LDS),
  *          mode 4: "pool_k" (1..4), "pool_refill", "pool_blas_min" (1..256), "pool_blas_exit", "pool_inloop",
  *                  "pool_other_min" (1..64),
- *          "blas_leaf_max" (1..8: triangles per BVH leaf, default 4 or the environment variable URT_BLAS_LEAF_MAX read when the
+ *          "blas_leaf_max" (1..8: triangles per BVH leaf, default 2 or the environment variable URT_BLAS_LEAF_MAX read when the
  *          library is loaded — a process-wide builder setting; rebuilds the BVH),
  *          "stack_pad" (0..96: test hook, unused extra entries per traversal stack -> the > 64 KiB LDS launch path),
  *          "qnodes" (0 off, the default | 1 on | -1 on unless some MeshObject spans fewer than 1024 grid cells: the traversal loop of the default

@@ -89,7 +89,7 @@ SCHED_VARIANTS = [
     {"front_list": 2},                                        # the listed FRONT (the default for this scene is the masked one)
     {"front_list": 0},                                        # neither: the heap walk with the BVH top inside it
 ]
-SCHED_DEFAULTS = {"sched_block": 0, "top_nodes": 64, "top_front": -1, "lds_tlas": 1, "tile_order": -1, "xcd_run": 0,
+SCHED_DEFAULTS = {"sched_block": 0, "top_nodes": -1, "top_front": -1, "lds_tlas": 1, "tile_order": -1, "xcd_run": 0,
                   "refill_min": 16, "blas_min": 0, "blas_exit": 0, "waves_per_cu": 0, "shade_min": 32, "front_list": -1}
 
 
@@ -131,7 +131,7 @@ def test_many_meshes_beyond_the_lds_tables(gpu_ctx):
             assert_same(gpu, ref, f"many meshes, top_nodes {tn} top_front {tf}")
             assert gc["blas_nodes"] == oc["blas_nodes"] and gc["tri_tests"] == oc["tri_tests"] and gc["watchdog_trips"] == 0
     finally:
-        gpu_ctx.set_option("top_nodes", 64); gpu_ctx.set_option("top_front", -1)
+        gpu_ctx.set_option("top_nodes", -1); gpu_ctx.set_option("top_front", -1)
 
 
 def test_deep_stacks_use_the_large_lds_launch_path(gpu_ctx):
@@ -170,7 +170,7 @@ def test_chain_shaped_triangle_bvh_fills_the_traversal_stack(gpu_ctx):
             for k in ("rays", "blas_nodes", "tri_tests"):
                 assert gc[k] == oc[k], (mode, k, gc[k], oc[k])
     finally:
-        gpu_ctx.set_option("blas_leaf_max", 4)
+        gpu_ctx.set_option("blas_leaf_max", 2)
 
 
 @pytest.mark.parametrize("k", [1, 2, 3, 4])

@@ -45,10 +45,14 @@ struct Box {
 };
 
 constexpr int kBins = 16;
+// Two triangles per leaf: a leaf trip of the traversal loop is then always ONE round of two Moller-Trumbore tests (no second round for
+// the lanes with bigger leaves), and node steps are the cheap body since the centre-form slab test.  Measured with the final kernels
+// (profiles/r03_logs/r3_sweep_leaf_max.log): 4 -> 2 triangles: C3 -3.0 %, C3D -3.0 %, C4 -2.2 %, C5 -4.2 % frame time; 1: +5 ... +10 %.
+constexpr int kLeafMaxDefault = 2;
 int leaf_max_from_env() {
   const char* e = std::getenv("URT_BLAS_LEAF_MAX");
-  int v = e ? std::atoi(e) : 4;
-  return v >= 1 && v <= 8 ? v : 4;
+  int v = e ? std::atoi(e) : kLeafMaxDefault;
+  return v >= 1 && v <= 8 ? v : kLeafMaxDefault;
 }
 int g_leaf_max = leaf_max_from_env();   // SAH leaves (tunable: URT_BLAS_LEAF_MAX at load time / urt_set_option "blas_leaf_max")
 constexpr int kLeafHardMax = 8;  // encoding limit (3 bits)

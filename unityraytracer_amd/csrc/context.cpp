@@ -148,7 +148,8 @@ struct urt_context {
                                             // profiles/r03_logs/r3_probe_tile_order.log; any order draws the same pixels
   int opt_lds_tlas = 1;                     // kernel_mode 3: object-level heaps, roots and spheres in LDS when small
   int opt_top_front = -1;                   // kernel_mode 3: top-of-forest walk inside the object-level phase (-1 = when the scene has several meshes)
-  int opt_top_nodes = 64;                   // kernel_mode 3: triangle-BVH nodes kept in LDS (0 = none)
+  int opt_top_nodes = -1;                   // kernel_mode 3: triangle-BVH nodes kept in LDS (0 = none; -1 = auto: 64, or with the masked object-level phase twice the number of
+                                            // MeshObjects that have a BVH, rounded up to a power of two — there the top is walked lane by lane inside that phase and only its first level pays)
 
   // ---- frame batching (kernel_mode 3) --------------------------------------------------------------------------------
   // A 1080p frame is small for this chip: ~40 % of its kernel time is the drain of the last long paths.
@@ -823,7 +824,7 @@ int auto_run_length(const FrameParams& P, int n_frames) {
 int configure_sched(urt_context* ctx, const DevScene& S, FrameParams& P, bool top_in_front) {
   // independent waves; the waves of a workgroup share one LDS copy of the top of the triangle-BVH forest, which shrinks
   // until 5 waves/SIMD (what 96 VGPRs allow) fit the 160 KiB of a CU next to their traversal stacks
-  int t = std::min(std::min(ctx->opt_top_nodes, (int)kTopOrderNodes), ctx->n_blas_nodes);
+  int t = std::min(std::min(ctx->opt_top_nodes >= 0 ? ctx->opt_top_nodes : 64, (int)kTopOrderNodes), ctx->n_blas_nodes);
   // small object-level tables (<= 256 entries) also live in LDS: their walk is a chain of dependent fetches
   P.lds_mesh = ctx->opt_lds_tlas && S.n_mesh_tlas > 0 && S.n_mesh_tlas <= 256 && S.n_meshes <= 256;
   P.lds_small = P.lds_mesh && S.n_small > 0;
@@ -842,11 +843,25 @@ int configure_sched(urt_context* ctx, const DevScene& S, FrameParams& P, bool to
   bool listed = top_in_front && P.top_nodes > 0 && P.lds_mesh && S.n_meshes <= 12 && ctx->opt_front_list != 0;
   // masked FRONT (kernels.hip front_masked): mesh heaps of <= 31 nodes are walked with mask arithmetic instead of a stack; the walk
   // table takes the heap's place in LDS.  "front_list" 2 forces the listed form (A/B), -1 / 1 prefer the masked one.
-  bool masked = top_in_front && P.top_nodes > 0 && ctx->opt_lds_tlas && ctx->walk_f4 > 0 && !P.serve && ctx->opt_front_list != 0 && ctx->opt_front_list != 2;
+  bool masked = top_in_front && t > 0 && ctx->opt_lds_tlas && ctx->walk_f4 > 0 && !P.serve && ctx->opt_front_list != 0 && ctx->opt_front_list != 2;
   if (masked) {
+    // The masked walk keeps no object-level stack for the mesh heap: the lane's `tl` column only serves the sphere heap's walk.  The
+    // entries that frees (C4, C5: 4 of 6, i.e. 4 KiB per workgroup) go to the LDS copy of the top of the forest, which is sized again for this layout.
     FrameParams Q = P;
     Q.lds_mesh = 0; Q.walk_f4 = ctx->walk_f4; Q.lds_small = S.n_small > 0;
-    if (sched_lds_bytes(S, Q) * groups <= budget) { P = Q; return 3; }
+    Q.tlas_stack = std::max(2, heap_levels(S.n_sphere_tlas) + 1);
+    Q.top_nodes = t;
+    if (ctx->opt_top_nodes < 0) {
+      // measured (profiles/r03_logs/r3_sweep_top_masked.log): C4 (3 big MeshObjects) 2.97 / 2.99 / 3.01 / 3.06 ms at a top of 4 / 8 / 16 / 64 nodes,
+      // C5 (12) 1.57 / 1.52 / 1.50 / 1.495 / 1.50 at 4 / 8 / 16 / 32 / 64: the roots and about one more level
+      int big = 0;
+      for (int32_t r : ctx->h_mesh_root) big += r >= 0 && r != kEmptyMeshRoot;
+      int want = 4;
+      while (want < 2 * big && want < 64) want *= 2;
+      Q.top_nodes = std::min(t, want);
+    }
+    while (Q.top_nodes > 0 && sched_lds_bytes(S, Q) * groups > budget) Q.top_nodes /= 2;
+    if (Q.top_nodes > 0 && sched_lds_bytes(S, Q) * groups <= budget) { P = Q; return 3; }
   }
   return listed ? 2 : (top_in_front && P.top_nodes > 0) ? 1 : 0;
 }
@@ -1650,7 +1665,7 @@ int urt_set_option(urt_context* ctx, const char* name, int value) {
     if (value < -1 || value > 1) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "top_front must be -1 (auto), 0 or 1");
     ctx->opt_top_front = value;
   } else if (std::strcmp(name, "top_nodes") == 0) {
-    if (value < 0 || value > kTopOrderNodes) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "top_nodes must be in [0, 256]");
+    if (value < -1 || value > kTopOrderNodes) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "top_nodes must be in [0, 256], or -1 (auto)");
     ctx->opt_top_nodes = value;
   } else if (std::strcmp(name, "pool_k") == 0) {
     if (value < 1 || value > 4) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "pool_k must be in [1, 4]");

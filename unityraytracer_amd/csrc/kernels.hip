@@ -118,10 +118,22 @@ __device__ __forceinline__ void test_leaf(const DevScene& S, int32_t leaf, v3 o,
   uint32_t code = ~(uint32_t)leaf;
   uint32_t first = code >> 3, cnt = (code & 7u) + 1u;
   if (lds_first >= 0) {
+#ifdef URT_LDS_LEAF_SINGLE                   // A/B build: one record at a time (rounds 2-3)
     for (uint32_t k = 0; k < cnt; k++) {
       const float4* t = lds_tris + 3 * ((uint32_t)lds_first + k);
       test_triangle<COUNT>(t[0], t[1], t[2], (int)(first + k), o, d, best, best_i, lc);
     }
+#else
+    for (uint32_t k = 0; k < cnt; k += 2) {            // two records per round, both read before either is tested (a wall quad is one round)
+      const bool two = k + 1 < cnt;
+      const float4* ta = lds_tris + 3 * ((uint32_t)lds_first + k);
+      const float4* tb = lds_tris + 3 * ((uint32_t)lds_first + k + (two ? 1u : 0u));
+      float4 a0 = ta[0], a1 = ta[1], a2 = ta[2];
+      float4 b0 = tb[0], b1 = tb[1], b2 = tb[2];
+      test_triangle<COUNT>(a0, a1, a2, (int)(first + k), o, d, best, best_i, lc);
+      if (two) test_triangle<COUNT>(b0, b1, b2, (int)(first + k + 1), o, d, best, best_i, lc);
+    }
+#endif
     return;
   }
   // two triangles per round: both records are requested before either is tested, so a leaf of 4 costs two memory

@@ -15,7 +15,7 @@ struct LbvhInput {
   const float* normals = nullptr; int n_normals = 0;            // _Normals (may be null)
   // HOST copies of each MeshObject's (indices_offset, indices_count): they lay out the per-mesh segments
   const int32_t* h_offsets = nullptr; const int32_t* h_counts = nullptr;
-  int leaf_max = 4;                                             // triangles per leaf (1..8)
+  int leaf_max = 2;                                             // triangles per leaf (1..8)
 };
 
 struct LbvhOutput {
