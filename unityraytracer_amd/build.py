@@ -46,7 +46,7 @@ def build_variant(out: str, defines, verbose: bool = False) -> str:
     objs, jobs = [], []
     for src in srcs:
         name = os.path.basename(src)
-        if name in ("kernels.hip", "context.cpp") or not os.path.exists(os.path.join(base, name + ".o")):   # the rest does not depend on the defines
+        if name in ("kernels.hip", "context.cpp", "blas_builder.cpp") or not os.path.exists(os.path.join(base, name + ".o")):   # the rest does not depend on the defines
             obj = os.path.join(objdir, name + ".o")
             jobs.append([hipcc] + cflags + ["-c", src, "-o", obj])
         else:

@@ -44,7 +44,10 @@ struct Box {
   }
 };
 
-constexpr int kBins = 16;
+#ifndef URT_SAH_BINS
+#define URT_SAH_BINS 32
+#endif
+constexpr int kBins = URT_SAH_BINS;
 // Two triangles per leaf: a leaf trip of the traversal loop is then always ONE round of two Moller-Trumbore tests (no second round for
 // the lanes with bigger leaves), and node steps are the cheap body since the centre-form slab test.  Measured with the final kernels
 // (profiles/r03_logs/r3_sweep_leaf_max.log): 4 -> 2 triangles: C3 -3.0 %, C3D -3.0 %, C4 -2.2 %, C5 -4.2 % frame time; 1: +5 ... +10 %.
@@ -151,6 +154,12 @@ struct Builder {
       if (n <= kLeafHardMax && best_axis < 0) return make_leaf(lo, hi);
       mid = (lo + hi) / 2;   // median by current order: keeps the tree finite for degenerate input
     }
+    return emit(lo, mid, hi, depth);
+  }
+
+  // the node over prims[lo, mid) | prims[mid, hi): builds both subtrees (on another thread when the node is big and one is idle) and writes their padded boxes
+  int32_t emit(int lo, int mid, int hi, int depth) {
+    const int n = hi - lo;
     int32_t me = (int32_t)(nodes.size() / kBlasNodeFloats);
     nodes.resize(nodes.size() + kBlasNodeFloats, 0.0f);
     Box b0, b1;
