@@ -546,6 +546,19 @@ void oracle_math_probe(int fn, const float* a, const float* b, const float* c, f
   }
 }
 
+// The triangle-BVH slab test on centre / half-extent boxes (include/urt_math.h box_center_form, cray, cslab): n boxes (lo3 hi3 each) against n
+// rays (origin3 direction3 each) and best t; writes c3 h3 per box and t_near, t_far per pair (tests/test_oracle_geometry.py checks containment and
+// conservativeness in exact arithmetic).
+void oracle_probe_cslab(const float* boxes6, const float* rays6, const float* tbest, float* ch6, float* tnf2, int n) {
+  for (int i = 0; i < n; i++) {
+    float c[3], h[3];
+    box_center_form(boxes6 + 6 * i, boxes6 + 6 * i + 3, c, h);
+    for (int k = 0; k < 3; k++) { ch6[6 * i + k] = c[k]; ch6[6 * i + 3 + k] = h[k]; }
+    const CRay R = cray(ld3(rays6 + 6 * i), ld3(rays6 + 6 * i + 3));
+    cslab(c[0], c[1], c[2], h[0], h[1], h[2], R, tbest[i], tnf2[2 * i], tnf2[2 * i + 1]);
+  }
+}
+
 // Exhaustive check of urt::f_div_const (include/urt_math.h) against the IEEE quotient: every float bit pattern x (both signs,
 // zeros, denormals, infinities, NaNs) for the constant c.  Returns the number of x whose results differ in any bit.
 unsigned long long oracle_check_div_const(float c, int n_threads) {

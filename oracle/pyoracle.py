@@ -65,6 +65,8 @@ def load(build: bool = True):
     lib.oracle_check_div_const.restype = C.c_ulonglong
     lib.oracle_probe_triangle.argtypes = [vp, vp, vp, vp, vp]
     lib.oracle_probe_triangle.restype = i
+    lib.oracle_probe_cslab.argtypes = [vp, vp, vp, vp, vp, i]
+    lib.oracle_probe_cslab.restype = None
     lib.oracle_probe_aabb.argtypes = [vp, vp]
     lib.oracle_probe_aabb.restype = i
     lib.oracle_probe_trace.argtypes = [C.POINTER(OracleScene), i, vp, vp]
@@ -190,6 +192,20 @@ def math_probe(fn: str, a, b=None, c=None) -> np.ndarray:
     out = np.zeros_like(a)
     lib.oracle_math_probe(ids[fn], _ptr(a), _ptr(b), _ptr(c), _ptr(out), a.size)
     return out
+
+
+def probe_cslab(boxes, rays, tbest):
+    """(c, h)[n, 6] and (t_near, t_far)[n, 2] of the product's triangle-BVH slab test for n boxes (lo3 hi3) x n rays (origin3 direction3)."""
+    lib = load()
+    boxes = np.ascontiguousarray(boxes, dtype=np.float32).reshape(-1, 6)
+    rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
+    tb = np.ascontiguousarray(tbest, dtype=np.float32).reshape(-1)
+    n = len(boxes)
+    assert len(rays) == n and len(tb) == n
+    ch = np.zeros((n, 6), np.float32)
+    tnf = np.zeros((n, 2), np.float32)
+    lib.oracle_probe_cslab(_ptr(boxes), _ptr(rays), _ptr(tb), _ptr(ch), _ptr(tnf), n)
+    return ch, tnf
 
 
 def check_div_const(c: float, threads: int = 8) -> int:

@@ -139,3 +139,84 @@ def test_accumulate_running_mean():                         # AS:9,39-41 / RM:81
         assert np.allclose(conv[..., :3], frames[: n + 1, ..., :3].mean(axis=0), rtol=1e-5, atol=1e-6)
     first = pyoracle.accumulate(frames[0], np.full((6, 7, 4), 123.0, np.float32), 0)
     assert np.array_equal(first[..., :3], frames[0][..., :3]) and np.all(first[..., 3] == 1.0)
+
+
+# ---- the triangle-BVH slab test on centre / half-extent boxes (include/urt_math.h box_center_form, cray, cslab) ---------------------------
+def _random_boxes(rng, n):
+    scale = 10.0 ** rng.uniform(-3, 6, (n, 1))
+    centre = rng.normal(size=(n, 3)) * scale
+    ext = np.abs(rng.normal(size=(n, 3))) * scale * 10.0 ** rng.uniform(-6, 0, (n, 1))
+    ext[rng.random((n, 3)) < 0.1] = 0.0                                  # flat boxes (axis-aligned quads)
+    lo = (centre - ext).astype(np.float32)
+    hi = (centre + ext).astype(np.float32)
+    return np.minimum(lo, hi), np.maximum(lo, hi)
+
+
+def test_centre_form_boxes_contain_the_lo_hi_boxes():
+    """box_center_form: [c - h, c + h] contains [lo, hi] in EXACT arithmetic for boxes from 1e-3 to 1e6 units, flat ones included;
+    it widens them by at most a few ulp; an inverted (empty) box gets a negative half extent (no ray enters it)."""
+    from fractions import Fraction as Fr
+    rng = np.random.default_rng(11)
+    lo, hi = _random_boxes(rng, 4000)
+    rays = np.tile(np.array([0, 0, -5, 0, 0, 1], np.float32), (len(lo), 1))
+    ch, _ = pyoracle.probe_cslab(np.hstack([lo, hi]), rays, np.full(len(lo), np.inf, np.float32))
+    c, h = ch[:, :3], ch[:, 3:]
+    for i in range(len(lo)):
+        for a in range(3):
+            cc, hh = Fr(float(c[i, a])), Fr(float(h[i, a]))
+            assert cc - hh <= Fr(float(lo[i, a])) and cc + hh >= Fr(float(hi[i, a])), (i, a, lo[i], hi[i], c[i], h[i])
+    slack = (h.astype(np.float64) * 2 - (hi.astype(np.float64) - lo.astype(np.float64)))
+    size = np.maximum(np.abs(lo), np.abs(hi)).astype(np.float64)
+    assert np.all(slack <= 1.5e-6 * size + 1e-36)                       # a few ulp of the coordinates (2^-21 relative + the rounding of c), not more
+    inv_lo, inv_hi = hi.copy(), lo.copy()
+    inv_lo[:, 0] = hi[:, 0] + 1.0; inv_hi[:, 0] = lo[:, 0]               # lo.x > hi.x: the builders' empty box
+    ch, tnf = pyoracle.probe_cslab(np.hstack([inv_lo, inv_hi]), rays, np.full(len(lo), np.inf, np.float32))
+    assert np.all(ch[:, 3:] < 0) and np.all(~(tnf[:, 0] <= tnf[:, 1]))
+
+
+def test_centre_form_slab_test_never_misses_a_box_the_ray_enters():
+    """Conservativeness of cslab, one-sided: a float32 ray that (in exact arithmetic) passes through the box SHRUNK by 2^-18 of the
+    coordinates involved, within [0, 0.999 tbest], is reported as entering it — also rays with exactly zero direction components,
+    origins inside the box, and boxes far from the origin.  (The margin is 1/4 of the per-ray pad the test adds, 2^-16 max|o|, plus the
+    build-time pad real nodes carry; a miss here would be a triangle the traversal could skip.)"""
+    from fractions import Fraction as Fr
+    rng = np.random.default_rng(12)
+    n = 3000
+    lo, hi = _random_boxes(rng, n)
+    lo64, hi64 = lo.astype(np.float64), hi.astype(np.float64)
+    target = lo64 + rng.random((n, 3)) * (hi64 - lo64)                   # a point of the box
+    dist = 10.0 ** rng.uniform(-2, 3, (n, 1)) * np.maximum(1e-3, np.abs(target).max(axis=1, keepdims=True))
+    direction = rng.normal(size=(n, 3)); direction /= np.linalg.norm(direction, axis=1, keepdims=True)
+    axis_par = rng.random(n) < 0.15
+    for i in np.nonzero(axis_par)[0]:
+        direction[i, rng.integers(0, 3)] = 0.0
+        direction[i] /= np.linalg.norm(direction[i])
+    origin = (target - direction * dist).astype(np.float32)
+    inside = rng.random(n) < 0.1
+    origin[inside] = target[inside].astype(np.float32)                    # the ray starts inside the box
+    d32 = direction.astype(np.float32)
+    rays = np.hstack([origin, d32])
+    tbest = np.where(rng.random(n) < 0.5, np.inf, (dist[:, 0] * 4 + 1)).astype(np.float32)
+    _, tnf = pyoracle.probe_cslab(np.hstack([lo, hi]), rays, tbest)
+    hit = tnf[:, 0] <= tnf[:, 1]
+    checked = 0
+    for i in range(n):
+        o = [Fr(float(x)) for x in origin[i]]
+        d = [Fr(float(x)) for x in d32[i]]
+        m = Fr(float(max(np.abs(lo[i]).max(), np.abs(hi[i]).max(), np.abs(origin[i]).max()))) / (1 << 18)
+        t0, t1 = Fr(0), (Fr(float(tbest[i])) * Fr(999, 1000) if np.isfinite(tbest[i]) else Fr(10) ** 30)
+        ok = True
+        for a in range(3):
+            l, h = Fr(float(lo[i, a])) + m, Fr(float(hi[i, a])) - m
+            if l > h:
+                ok = False; break                                         # the shrunk box is empty on this axis: nothing to demand
+            if d[a] == 0:
+                if not (l <= o[a] <= h): ok = False; break
+            else:
+                ta, tb = (l - o[a]) / d[a], (h - o[a]) / d[a]
+                t0, t1 = max(t0, min(ta, tb)), min(t1, max(ta, tb))
+                if t0 > t1: ok = False; break
+        if ok:
+            checked += 1
+            assert hit[i], (i, origin[i], d32[i], lo[i], hi[i], tbest[i], tnf[i])
+    assert checked > n // 3                                               # the property was exercised, not vacuous
