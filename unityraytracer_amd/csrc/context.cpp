@@ -92,6 +92,7 @@ struct urt_context {
   int opt_refit = 1;                        // 0 = always prepare from scratch
   int opt_qnodes = 0;                       // 32-byte quantized nodes in the traversal loop: 0 = off (default: measured -1.3 % on C3 / C3D, +1.3 % on C4 / C5 — the loop waits on the latency of ONE dependent fetch per step, not on its width), 1 = on, -1 = on unless a MeshObject is only a few grid cells wide
   float4* qbuf = nullptr;                   // frame + quantized nodes of the prepared scene (in scene_allocs)
+  int sched_groups = 0;                     // kernel_mode 3: workgroups per CU the last configuration counts on when fewer than the default fit (0 = default)
   float4* cbuf = nullptr;                   // centre / half-extent copy of the nodes of the prepared scene (in scene_allocs): DevScene::blas_cnodes
   float qnode_quality = 0;                  // smallest MeshObject extent in grid cells (csrc/qnodes.hip)
   std::vector<uint8_t> prev_mesh_objects;   // the _MeshObjects records of the prepared scene
@@ -819,25 +820,21 @@ int auto_run_length(const FrameParams& P, int n_frames) {
   return g;
 }
 
-// kernel_mode 3: what lives in the workgroup's LDS next to the stacks (fills P.top_nodes, P.lds_*, P.block_threads, P.list_base,
-// P.tlas_stack) and how FRONT treats MeshObjects (returns the front mode of kernels.h launch_sched)
-int configure_sched(urt_context* ctx, const DevScene& S, FrameParams& P, bool top_in_front) {
+// One attempt at `groups` workgroups per CU; *degraded = an LDS feature the scene qualifies for had to be given up (or the stacks alone do not fit)
+static int configure_sched_at(urt_context* ctx, const DevScene& S, FrameParams& P, bool top_in_front, size_t groups, bool* degraded) {
   // independent waves; the waves of a workgroup share one LDS copy of the top of the triangle-BVH forest, which shrinks
-  // until 5 waves/SIMD (what 96 VGPRs allow) fit the 160 KiB of a CU next to their traversal stacks
+  // until the workgroups fit the 160 KiB of a CU next to their traversal stacks
   int t = std::min(std::min(ctx->opt_top_nodes >= 0 ? ctx->opt_top_nodes : 64, (int)kTopOrderNodes), ctx->n_blas_nodes);
   // small object-level tables (<= 256 entries) also live in LDS: their walk is a chain of dependent fetches
   P.lds_mesh = ctx->opt_lds_tlas && S.n_mesh_tlas > 0 && S.n_mesh_tlas <= 256 && S.n_meshes <= 256;
   P.lds_small = P.lds_mesh && S.n_small > 0;
   P.lds_sphere = ctx->opt_lds_tlas && S.n_sphere_tlas > 0 && S.n_sphere_tlas <= 256 && S.n_spheres <= 256;
-  bool shared = t > 0 || P.lds_mesh || P.lds_sphere;
-  P.block_threads = ctx->opt_sched_block > 0 ? ctx->opt_sched_block : (shared ? 256 : 64);   // nothing to share: single waves
-  if (P.serve) P.block_threads = 256;                        // kernel_mode 5: the waves of a workgroup share the traversal service
+  const bool wanted_tables = P.lds_mesh || P.lds_sphere;
   P.top_nodes = t;
-  const int wpc_default = P.serve ? 16 : 20;                 // what the kernel's registers allow (k_serve: 128 VGPRs, k_sched: 96)
-  size_t groups = std::max<size_t>(1, (size_t)(ctx->opt_waves_per_cu > 0 ? ctx->opt_waves_per_cu : wpc_default) / (size_t)(P.block_threads / 64));   // workgroups per CU that must fit
   const size_t budget = 156 * 1024;                          // (a little of the 160 KiB goes to allocation granules)
   while (P.top_nodes > 0 && sched_lds_bytes(S, P) * groups > budget) P.top_nodes /= 2;
   if (sched_lds_bytes(S, P) * groups > budget) { P.lds_mesh = 0; P.lds_sphere = 0; P.lds_small = 0; }
+  *degraded = (t > 0 && P.top_nodes == 0) || (wanted_tables && !(P.lds_mesh || P.lds_sphere)) || sched_lds_bytes(S, P) * groups > budget;
   // listed FRONT (kernels.hip front_listed): scenes of a few MeshObjects whose heap is in LDS; the list of objects a ray has to test
   // (<= 12 ids of 5 bits) lives in the first two entries of the lane's object-level stack, so it costs no LDS
   bool listed = top_in_front && P.top_nodes > 0 && P.lds_mesh && S.n_meshes <= 12 && ctx->opt_front_list != 0;
@@ -861,9 +858,42 @@ int configure_sched(urt_context* ctx, const DevScene& S, FrameParams& P, bool to
       Q.top_nodes = std::min(t, want);
     }
     while (Q.top_nodes > 0 && sched_lds_bytes(S, Q) * groups > budget) Q.top_nodes /= 2;
-    if (Q.top_nodes > 0 && sched_lds_bytes(S, Q) * groups <= budget) { P = Q; return 3; }
+    if (Q.top_nodes > 0 && sched_lds_bytes(S, Q) * groups <= budget) { P = Q; *degraded = false; return 3; }
+    *degraded = true;
   }
   return listed ? 2 : (top_in_front && P.top_nodes > 0) ? 1 : 0;
+}
+
+// kernel_mode 3: what lives in the workgroup's LDS next to the stacks (fills P.top_nodes, P.lds_*, P.block_threads, P.list_base,
+// P.tlas_stack), how many workgroups per CU the launch counts on (ctx->sched_groups) and how FRONT treats MeshObjects (returns the
+// front mode of kernels.h launch_sched).  5 waves per SIMD (what 96 VGPRs allow) = 5 workgroups of 4 waves per CU is the target; a scene
+// whose traversal stacks are too deep for that (a GPU-built Morton tree of 100 k triangles is 30 levels: 34 KiB of stacks per workgroup)
+// keeps its LDS features — the masked object-level phase, the tables, the top of the forest — at 4 or 3 workgroups per CU instead
+// of losing them at a nominal 5 that the hardware would not make resident anyway (GPU-built trees: C4 6.71 -> 3.61 ms, C3 0.284 -> 0.264, C3D 0.502 -> 0.443; profiles/r03_logs/r3_lbvh_groups.log).
+int configure_sched(urt_context* ctx, const DevScene& S, FrameParams& P, bool top_in_front) {
+  {
+    const int t = std::min(std::min(ctx->opt_top_nodes >= 0 ? ctx->opt_top_nodes : 64, (int)kTopOrderNodes), ctx->n_blas_nodes);
+    const bool lds_mesh = ctx->opt_lds_tlas && S.n_mesh_tlas > 0 && S.n_mesh_tlas <= 256 && S.n_meshes <= 256;
+    const bool lds_sphere = ctx->opt_lds_tlas && S.n_sphere_tlas > 0 && S.n_sphere_tlas <= 256 && S.n_spheres <= 256;
+    const bool shared = t > 0 || lds_mesh || lds_sphere;
+    P.block_threads = ctx->opt_sched_block > 0 ? ctx->opt_sched_block : (shared ? 256 : 64);   // nothing to share: single waves
+    if (P.serve) P.block_threads = 256;                        // kernel_mode 5: the waves of a workgroup share the traversal service
+  }
+  const int wpc_default = P.serve ? 16 : 20;                 // what the kernel's registers allow (k_serve: 128 VGPRs, k_sched: 96)
+  const size_t per = (size_t)(P.block_threads / 64);
+  const size_t groups = std::max<size_t>(1, (size_t)(ctx->opt_waves_per_cu > 0 ? ctx->opt_waves_per_cu : wpc_default) / per);   // workgroups per CU that should fit
+  ctx->sched_groups = 0;
+  const FrameParams P0 = P;
+  bool degraded = false;
+  int mode = configure_sched_at(ctx, S, P, top_in_front, groups, &degraded);
+  if (degraded && ctx->opt_waves_per_cu <= 0 && per == 4) {
+    for (size_t g = groups - 1; g >= 3 && g + 2 >= groups; g--) {
+      FrameParams Q = P0; bool d2 = false;
+      int m2 = configure_sched_at(ctx, S, Q, top_in_front, g, &d2);
+      if (!d2) { P = Q; mode = m2; ctx->sched_groups = (int)g; break; }
+    }
+  }
+  return mode;
 }
 
 // Launch the phase-scheduled trace kernel for P.n_frames frames (uniforms T) into result + f * P.frame_stride.
@@ -891,6 +921,7 @@ int launch_sched_frames(urt_context* ctx, const DevScene& S, const FrameParams& 
   // (kernels.hip wave_fetch_pixels) the full 20 win at every frame size measured (profiles/README.md).
   int wpc = ctx->opt_waves_per_cu;
   if (wpc <= 0) wpc = P.serve ? 16 : 20;
+  if (ctx->sched_groups > 0) wpc = ctx->sched_groups * waves_per_block;       // deep stacks: fewer workgroups per CU, LDS features kept (configure_sched)
   long resident = (long)ctx->n_cus * wpc / waves_per_block;
   int nb = (int)std::max(1L, std::min(want, resident));
   if (P.serve) {                                             // mailbox of the posted rays: 32 B per thread of the grid
