@@ -149,6 +149,32 @@ def test_deep_stacks_use_the_large_lds_launch_path(gpu_ctx):
         gpu_ctx.set_option("stack_pad", 0)
 
 
+def test_masked_phase_at_fewer_workgroups_per_cu(gpu_ctx):
+    """Deep traversal stacks in a multi-mesh scene (C4 in small: Cornell box + 3 blobs, masked object-level phase): when 5 workgroups of
+    stacks no longer fit a CU's LDS, the launch counts on 4 or 3 and keeps the masked phase and the LDS copies (context.cpp
+    configure_sched) before it falls back to the large-LDS path.  `stack_pad` walks through all of these layouts; the GPU-built
+    (deeper) tree is one of them for real.  Pixels and counters == oracle in each."""
+    sc = scenes.config4(160, 90, slices=40, stacks=31, sky=scenes.make_sky(64, 32))
+    sc.num_bounces = 4
+    o = oracle_for(sc)
+    ref, oc = o.render(mode=1, threads=8, counters=True)
+    try:
+        for pad in (0, 4, 8, 12, 16, 24, 40):
+            gpu_ctx.set_option("stack_pad", pad)
+            gpu, _, gc = render_gpu(gpu_ctx, sc, 3, count=True)
+            assert_same(gpu, ref, f"C4 small, stack_pad {pad}")
+            assert gc["watchdog_trips"] == 0
+            for k in ("rays", "tlas_nodes", "blas_nodes", "tri_tests"):
+                assert gc[k] == oc[k], (pad, k, gc[k], oc[k])
+        gpu_ctx.set_option("stack_pad", 0)
+        gpu_ctx.set_option("blas_builder", 1)                  # the GPU-built Morton tree: pixels only (its own tree, its own counts)
+        gpu, _, gc = render_gpu(gpu_ctx, sc, 3)
+        assert_same(gpu, ref, "C4 small, GPU-built tree")
+        assert gc["watchdog_trips"] == 0
+    finally:
+        gpu_ctx.set_option("stack_pad", 0); gpu_ctx.set_option("blas_builder", 0)
+
+
 def test_chain_shaped_triangle_bvh_fills_the_traversal_stack(gpu_ctx):
     """A triangle BVH that is a chain (one triangle per leaf, every split peels off the far end) is as deep as it has leaves, and a ray
     down its axis has the far child of EVERY level on its stack at once: the per-lane LDS stacks (depth + free slot + the sentinel
