@@ -16,10 +16,20 @@ aspect and camera (N=4 is 3840x2160, BASELINE's multi-GPU resolution), cut into 
 round-robin to the ranks (global pixel ids -> pixels identical to a single-GPU frame); each rank
 accumulates its strips locally and ONE gather per frame (RCCL via torch.distributed) brings them to rank 0.
 
-Rank 0 prints one JSON line.  Extra objects: `roofline` (dominant kernel = the trace kernel: algorithmic
-bytes from the kernels' own traversal counters / its HIP-event duration, against 8 TB/s HBM) and
-`cpu_baseline` (the scalar C++ oracle — a port, not the reference — timed on the host cores for a bounded
-sample of the same workload).
+`--scaling strong` keeps the frame FIXED (C3: 1920x1080; C4 / C5: BASELINE's 3840x2160 "tiled across 8 GPUs") and divides its strips
+among the N ranks; the line then says `"scaling": "strong"`.
+
+Rank 0 prints one JSON line.  Extra objects:
+  `roofline` — the dominant kernel (the trace kernel, named by the library: urt_debug_launch_info) against the roof that BINDS it.
+      SURVEY 8(d)'s algorithmic byte rate saturates on this path (the BVH top and the object tables are in LDS, the rest is
+      L2 / Infinity-Cache resident: it exceeds the HBM peak), so it is reported as `algorithmic` (with `frac_of_hbm_peak` and
+      `saturated`), the measured HBM side as `hbm` (counter traffic / launch time / 8 TB/s), and `bound` / `achieved` / `peak` / `frac`
+      are the VALU issue roof: VALU wave-instructions of the launch (committed SQ_INSTS_VALU pass of the same launch shape,
+      profiles/pmc_traffic.json) x 128 flop (a 64-lane fma) / the launch's HIP-event duration measured live here, against the
+      157.3 TFLOP/s f32 vector peak (= one wave64 VALU instruction per 2 cycles per SIMD, 1024 SIMDs, 2.4 GHz).  frac <= 1 by construction.
+  `cpu_baseline` — the scalar C++ oracle (a port, not the reference) timed on the host cores for a bounded sample of the same workload.
+URT_BENCH_VERIFY=1: after the timed region (outside it) the presented image is compared bit for bit with the oracle's accumulation of the
+same W + K frames (N = 1), or with a single-rank render (N > 1).
 """
 from __future__ import annotations
 
@@ -35,6 +45,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_PEAK_TFLOPS = 157.3       # same guide, "F32 (f32 in) 157.3 TF (= vector peak)": 256 CUs x 4 SIMDs x 32 lanes/cycle x 2 flop x 2.4 GHz,
+                               # i.e. one wave64 VALU instruction (priced as a 64-lane fma = 128 flop) per 2 cycles per SIMD
 
 # ALGORITHMIC bytes per counted event — SURVEY.md §8(d)'s table, the figure `roofline.achieved` / `frac` are computed from:
 #   28 B object-level BVHNode, S_node = 64 B triangle-BVH node (this build's node: two child boxes), S_tri = 36 B world-space
@@ -75,6 +87,12 @@ def main():
     ap.add_argument("--gather-every", type=int, default=1, help="multi-GPU: gather the accumulated strips to rank 0 after every K-th frame (and after the last); "
                     "1 = the frame-end gather of every frame (default); a gather overwrites the whole image, so K > 1 only lowers the rate at which rank 0 could present it")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="urt_set_option NAME VALUE before the run (A/B of library options with the bench's own metric; reported in config.options)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="multi-GPU: weak = the frame grows with N (default, the driver's scaling bench); strong = the config's own frame "
+                         "(C4 / C5: 3840x2160, BASELINE configs 4 / 5) is divided among the N ranks")
+    ap.add_argument("--gather-rgb", type=int, default=1,
+                    help="multi-GPU: 1 (default) = the frame-end gather moves RGB only (12 B per pixel): the alpha channel of the running mean is a "
+                         "function of the sample index alone (AS:40) and rank 0 writes it itself; 0 = all four channels (16 B per pixel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--clock-warmup-ms", type=float, default=60.0,
                     help="before the W warm-up steps: run the same step untimed for this long so that the GPU has left its idle clocks "
@@ -109,6 +127,9 @@ def main():
     # URT_DIST_BACKEND=gloo is a REHEARSAL mode for boxes with fewer GPUs than ranks (ranks share a card, the gather is
     # staged through host memory); the driver's real multi-GPU runs use nccl (= RCCL over xGMI), one GPU per rank.
     backend = os.environ.get("URT_DIST_BACKEND", "nccl")
+    if backend != "gloo" and world > torch.cuda.device_count():
+        raise SystemExit(f"bench.py --gpus {world}: this node shows {torch.cuda.device_count()} GPU(s); the nccl (RCCL) backend needs one GPU per rank. "
+                         "(URT_DIST_BACKEND=gloo is the rehearsal mode in which ranks share a card.)")
     dev_index = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
@@ -121,7 +142,10 @@ def main():
 
     # ---- workload --------------------------------------------------------------------------------
     base_w, base_h = (1920, 1080) if args.config in ("C2", "C3", "C3D") else (3840, 2160)
-    s = math.sqrt(world) if args.config in ("C2", "C3", "C3D") else math.sqrt(world / 8.0) if world > 1 else 1.0
+    if args.scaling == "strong":
+        s = 1.0                                                # the config's own frame, whatever N
+    else:
+        s = math.sqrt(world) if args.config in ("C2", "C3", "C3D") else math.sqrt(world / 8.0) if world > 1 else 1.0
     width, height = int(round(base_w * s)), int(round(base_h * s))
     scene = scenes.CONFIGS[args.config](width, height)
 
@@ -159,7 +183,15 @@ def main():
     if world > 1:
         burst = max(1, min(16, args.frames_per_launch if args.frames_per_launch else int(os.environ.get("URT_BENCH_BURST", "16"))))
         ctx.set_option("frames_per_launch", burst)
-        n_floats = strips.packed_rows(height, world) * width * 4
+        rgb = bool(args.gather_rgb)
+        n_floats = strips.packed_rows(height, world) * width * (3 if rgb else 4)
+        alpha_of = {}                                             # sample index -> alpha of the running mean after it (strips.running_mean_alpha)
+        slot_alpha = {}
+
+        def mean_alpha(sample):
+            if sample not in alpha_of:
+                alpha_of[sample] = strips.running_mean_alpha(range(sample + 1))
+            return alpha_of[sample]
         ring = 2 * burst
         packed = [torch.zeros(n_floats, dtype=torch.float32, device=device) for _ in range(ring)]
         gathered = [[torch.empty(n_floats, dtype=torch.float32, device=device) for _ in range(world)] for _ in range(ring)] if rank == 0 else [None] * ring
@@ -203,7 +235,10 @@ def main():
                 do_gather(slot)
                 if rank == 0:
                     for r in range(world):
-                        full.unpack_rows(r, world, gathered[slot][r].data_ptr(), stream=comm_stream.cuda_stream)
+                        if rgb:
+                            full.unpack_rows_rgb(r, world, gathered[slot][r].data_ptr(), slot_alpha[slot], stream=comm_stream.cuda_stream)
+                        else:
+                            full.unpack_rows(r, world, gathered[slot][r].data_ptr(), stream=comm_stream.cuda_stream)
                 ev_gather[slot].record(comm_stream)
         if not overlap:
             main_stream.wait_event(ev_gather[state["pending"][-1]])
@@ -221,7 +256,8 @@ def main():
         state["i"] = i + 1
         state["frames"] = state.get("frames", 0) + 1
         if (i + 1) % max(1, args.gather_every) == 0:
-            master._converged.pack_rows(rank, world, packed[slot].data_ptr()) # deferred behind them
+            master._converged.pack_rows(rank, world, packed[slot].data_ptr(), rgb=rgb)   # deferred behind them
+            slot_alpha[slot] = mean_alpha(master._currentSample - 1) if rgb else None
             state["pending"].append(slot)
             state["stale"] = False
         else:
@@ -234,7 +270,8 @@ def main():
         if world > 1:
             if state.get("stale"):
                 slot = (state["i"] - 1) % ring
-                master._converged.pack_rows(rank, world, packed[slot].data_ptr())
+                master._converged.pack_rows(rank, world, packed[slot].data_ptr(), rgb=rgb)
+                slot_alpha[slot] = mean_alpha(master._currentSample - 1) if rgb else None
                 state["pending"].append(slot)
                 state["stale"] = False
             submit()
@@ -286,9 +323,13 @@ def main():
     elapsed = float(t.item())
     total_rays = float(rays.item())
 
+    # ---- N = 1 verification against the oracle (URT_BENCH_VERIFY=1), outside the timed region: what `destination` holds now is the
+    # present of the last timed step = the running mean of frames 0 .. W+K-1 (the clock warm-up restarted the sequence) ----
+    verify_img = None
+    if world == 1 and os.environ.get("URT_BENCH_VERIFY") == "1":
+        verify_img = (destination.GetPixels(), master._converged.GetPixels())
+
     # ---- roofline of the dominant kernel (rank 0): replay the same frames with traversal counters on -----------
-    # `issue` (beside it): what bounds the kernel once SURVEY 8(d)'s byte fraction saturates (C2 / C3D exceed 1: the bytes come from
-    # LDS / L2) — VALU issue rate, lane utilisation and the share of wave cycles spent waiting, from the committed SQ_* passes
     roofline = None
     issue = None
     cpu = None
@@ -298,6 +339,7 @@ def main():
         kernel_ms = c["trace_ms"] / max(1, c["dispatches"])
         launch_ms = c["trace_ms"] / max(1, c["launches"])
         frames_per_launch = c["dispatches"] / max(1, c["launches"])
+        linfo = ctx.launch_info()                                      # the instantiation the library really launched (not a guess from the scene)
         ctx.set_option("count_stats", 1)
         ctx.set_option("time_dispatch", 0)
         master._frame = args.warmup
@@ -310,32 +352,56 @@ def main():
         alg_frame = algorithmic_bytes(cc) / max(1, cc["dispatches"])
         alg = alg_frame * frames_per_launch                            # per LAUNCH, like launch_ms
         padded = algorithmic_bytes(cc, BYTES_PADDED) / max(1, cc["dispatches"]) * frames_per_launch
-        achieved = alg / (launch_ms * 1e-3) / 1e9
-        # HBM-side traffic is NOT measured in this run (PMC needs rocprofv3): it is the committed figure of the last profiled
-        # build, per launch of the same shape, or null when that profile is of another configuration / batch size
-        traffic, traffic_source, issue = None, None, None
+        alg_rate = alg / (launch_ms * 1e-3) / 1e9
+        # Counter-side figures are NOT measured in this run (PMC needs rocprofv3): they are the committed passes of the last profiled
+        # build, per launch of the SAME shape (config and frames per launch), or null when no such profile exists
+        traffic, traffic_source, issue, valu_insts, pmc_kernel = None, None, None, None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")       # written from rocprofv3 --pmc passes (profiles/README.md)
-        if os.path.exists(pmc) and world == 1 and args.kernel_mode in (None, 3):
+        if os.path.exists(pmc) and world == 1 and args.kernel_mode in (None, 3) and not args.opt:
             try:
                 j = json.load(open(pmc)).get("configs", {}).get(args.config) or {}
                 j = (j.get("by_frames_per_launch") or {}).get(str(int(round(frames_per_launch))))     # the entry of THIS launch shape
                 if j:
                     traffic = j.get("hbm_bytes_per_launch")
-                    traffic_source = f"profiles/pmc_traffic.json ({j.get('round')}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `{j.get('command')}`, an earlier run of this launch shape — not measured in this run)"
+                    traffic_source = f"profiles/pmc_traffic.json ({j.get('round')}: separate rocprofv3 --pmc passes of `{j.get('command')}`, an earlier run of this launch shape — not measured in this run)"
                     issue = j.get("issue")
+                    valu_insts = (issue or {}).get("valu_insts_per_launch")
+                    if valu_insts is None and issue and issue.get("valu_insts_per_frame"):
+                        valu_insts = issue["valu_insts_per_frame"] * frames_per_launch
+                    pmc_kernel = j.get("kernel")
             except Exception:
                 traffic = None
-        # k_sched<COUNT, BLOCK, FMODE, MULTI>: FMODE 0 one mesh, 2 listed FRONT (2..12 MeshObjects), 1 more than that (kernels.hip)
-        n_mo = len(scene.mesh_objects)
-        kname = f"k_sched<false, 256, {0 if n_mo <= 1 else 2 if n_mo <= 12 else 1}, {'true' if scene.num_rays > 1 else 'false'}>"
-        roofline = {"bound": "hbm", "kernel": f"trace: {kname} (kernel_mode 3, the default)" if args.kernel_mode in (None, 3) else f"trace kernel of kernel_mode {args.kernel_mode}",
-                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": traffic, "traffic_source": traffic_source,
-                    "byte_table": "SURVEY.md 8(d): 28 B object node, 64 B BVH node, 36 B triangle, 16 B sphere, 76 B triangle hit, 40 B sphere hit, 16 B pixel",
-                    "algorithmic_bytes_per_launch": int(alg), "launch_ms": round(launch_ms, 4),
-                    "frames_per_launch": round(frames_per_launch, 2), "kernel_ms_per_frame": round(kernel_ms, 4),
-                    "padded_record_bytes_per_launch": int(padded), "frac_padded_records": round(padded / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                    "bytes_per_ray": round(alg_frame * cc["dispatches"] / max(1, cc["rays"]), 1)}
+        kname = linfo["kernel"]
+        if pmc_kernel and kname not in pmc_kernel:                     # the committed counters are of another instantiation: not this kernel's
+            traffic, traffic_source, issue, valu_insts = None, None, None, None
+        algorithmic = {"byte_table": "SURVEY.md 8(d): 28 B object node, 64 B BVH node, 36 B triangle, 16 B sphere, 76 B triangle hit, 40 B sphere hit, 16 B pixel",
+                       "bytes_per_launch": int(alg), "bytes_per_ray": round(alg_frame * cc["dispatches"] / max(1, cc["rays"]), 1),
+                       "rate": round(alg_rate, 1), "unit": "GB/s", "frac_of_hbm_peak": round(alg_rate / HBM_PEAK_GBS, 4),
+                       "saturated": bool(alg_rate >= 0.8 * HBM_PEAK_GBS),
+                       "note": "every counted node / triangle / hit record priced as if it came from HBM; the BVH top and the object tables are in LDS, "
+                               "the rest is L2 / Infinity-Cache resident, so this rate can exceed the HBM peak: it is a work rate, not a roofline",
+                       "padded_record_bytes_per_launch": int(padded)}
+        hbm = None
+        if traffic:
+            hbm = {"achieved": round(traffic / (launch_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": round(traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "bytes_per_launch": traffic,
+                   "over_algorithmic": round(traffic / max(1.0, alg), 3)}
+        common = {"kernel": kname, "kernel_mode": linfo["kernel_mode"], "launch_ms": round(launch_ms, 4), "frames_per_launch": round(frames_per_launch, 2),
+                  "kernel_ms_per_frame": round(kernel_ms, 4), "traffic": traffic, "traffic_source": traffic_source, "hbm": hbm, "algorithmic": algorithmic,
+                  "launch": {k: linfo[k] for k in ("front_mode", "n_blocks", "block_threads", "lds_bytes", "waves_per_cu", "xcd_run", "frame_group", "top_nodes", "slab_frames_max")}}
+        if valu_insts:
+            # the binding roof: VALU issue.  wave-instructions (committed SQ_INSTS_VALU of this launch shape) x 128 flop / live launch time
+            tf = valu_insts * 128.0 / (launch_ms * 1e-3) / 1e12
+            roofline = {"bound": "valu", "achieved": round(tf, 2), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / VALU_PEAK_TFLOPS, 4),
+                        "what": "VALU wave-instructions of the launch, each priced as a 64-lane fma (128 flop), against the f32 vector peak = one wave64 VALU "
+                                "instruction per 2 cycles per SIMD; the lanes that do useful work are `lane_util` of that",
+                        "valu_insts_per_launch": int(valu_insts), "lane_util": (issue or {}).get("lane_util"), **common}
+        else:
+            # no committed counters for this launch shape: the byte rate alone, flagged as saturated when it is; frac stays <= 1 or null
+            roofline = {"bound": "hbm", "achieved": round(alg_rate, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(alg_rate / HBM_PEAK_GBS, 4) if alg_rate < HBM_PEAK_GBS else None,
+                        "what": "algorithmic bytes / launch time (no committed PMC passes for this launch shape); null frac = the byte rate exceeds the HBM peak (cache-resident data)",
+                        **common}
 
         # ---- CPU baseline: the oracle (scalar C++ port) on the host cores, bounded sample -------------------------
         if world == 1 and not args.no_cpu_baseline:
@@ -367,6 +433,26 @@ def main():
                    "sample": f"{cpu_frames} frames of {scene.name} {width}x{height} ({dt:.1f} s wall on {cores} std::threads), BVH-culled scalar oracle; "
                              f"1-thread figure: a {height // 16}-row band of frame 0 ({dt1:.1f} s)"}
 
+    verified = None
+    if verify_img is not None:
+        # the oracle's accumulation of the same W + K frames (frame uniforms 0 .. W+K-1, AS:9,39-41 blend), bit for bit
+        import numpy as np
+        from oracle import pyoracle
+        from unityraytracer_amd import debug_build_blas
+        o = pyoracle.Oracle(scene)
+        if len(scene.mesh_objects):
+            nodes, tri, root, _, _ = debug_build_blas(scene.mesh_objects, scene.vertices, scene.indices)
+            o.set_blas(nodes, tri, root)
+        acc = None
+        for i in range(args.warmup + args.steps):
+            ox, oy, sd = (scene.pixel_offset[0], scene.pixel_offset[1], scene.seed) if i == 0 else scenes.frame_uniforms(i)
+            o.set_frame((ox, oy), sd)
+            img = o.render(mode=1, threads=min(pyoracle.hardware_threads(), usable_cores()))
+            acc = pyoracle.accumulate(img, acc if acc is not None else np.zeros_like(img), i)
+        verified = bool(np.array_equal(verify_img[0].view(np.uint32), acc.view(np.uint32)) and np.array_equal(verify_img[1].view(np.uint32), acc.view(np.uint32)))
+        print(f"[verify] destination and _converged after {args.warmup + args.steps} frames == the oracle's running mean: {verified}", file=sys.stderr, flush=True)
+        if not verified:
+            raise SystemExit("the presented image differs from the oracle's accumulation of the same frames")
     if world > 1 and os.environ.get("URT_BENCH_VERIFY") == "1":
         # rank 0 re-renders the LAST frame alone and compares the gathered, accumulated image bit for bit
         fence()
@@ -387,16 +473,17 @@ def main():
         out = {
             "metric": "Mrays/sec @1920x1080, 8 bounces", "value": round(total_rays / elapsed / 1e6, 2), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "present": True,     # the step includes RM:819's Graphics.Blit(_converged, destination) (N > 1: the gather into rank 0's image)
             "clock_warmup": clock_warmup,   # untimed steps run BEFORE the W warm-up steps to leave idle clocks (--clock-warmup-ms; 0 disables)
             "config": {"workload": f"{args.config}: {scene.name}, {scene.n_triangles} triangles + triangle BVH, {len(scene.spheres)} spheres, "
                                    f"ground plane, equirect sky; numBounces {scene.num_bounces}, numRays {scene.num_rays}",
                        "frame": [width, height], "pixels_per_gpu": width * height // world,
-                       "partition": (f"8-row strips round-robin over ranks, one gather per frame; {burst} frames per launch, each burst's gathers" + (" overlap the next burst's rendering" if overlap else " serialised")) if world > 1 else "single GPU",
+                       "partition": (f"8-row strips round-robin over ranks, one gather per frame ({'RGB, 12' if rgb else 'RGBA, 16'} B per pixel); {burst} frames per launch, each burst's gathers" + (" overlap the next burst's rendering" if overlap else " serialised")) if world > 1 else "single GPU",
                        "rays_per_step": int(total_rays / args.steps), "kernel_mode": args.kernel_mode if args.kernel_mode is not None else 3,
                        **({"gather_every": args.gather_every} if world > 1 else {}), **({"options": args.opt} if args.opt else {})},
             "roofline": roofline, "issue": issue, "cpu_baseline": cpu,
+            **({"verified_against_oracle": verified} if verified is not None else {}),
         }
         print(json.dumps(out), flush=True)
     master.OnDisable()

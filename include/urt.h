@@ -148,6 +148,15 @@ URT_API int urt_texture_unpack_rows(urt_context* ctx, urt_handle texture, int fi
  * gather target never is).  Lets rank 0 de-interleave frame i while its render stream is already on frame i+1. */
 URT_API int urt_texture_unpack_rows_on(urt_context* ctx, urt_handle texture, int first_group_row, int row_stride,
                                        const void* device_src, void* hip_stream);
+/* The RGB forms (12 B per pixel instead of 16) for the gather of a RUNNING MEAN: AdditionShader blends the alpha channel like the
+ * colours and its source alpha is a = 1 / (_Sample + 1) itself (AS:39-41), so after sample n the alpha of `_converged` is the same
+ * value in every pixel — w_0 = a_0 a_0, w_n = a_n a_n + w_{n-1} (1 - a_n) in float32 — and need not travel: the ranks pack three
+ * channels and the root passes that value as `alpha` when it de-interleaves.  hip_stream NULL = the context's own stream (deferred
+ * and ordered like urt_texture_unpack_rows), else a caller-ordered stream like urt_texture_unpack_rows_on. */
+URT_API int urt_texture_pack_rows_rgb(urt_context* ctx, urt_handle texture, int first_group_row, int row_stride,
+                                      void* device_dst, uint64_t* out_bytes);
+URT_API int urt_texture_unpack_rows_rgb(urt_context* ctx, urt_handle texture, int first_group_row, int row_stride,
+                                        const void* device_src, float alpha, void* hip_stream);
 
 /* ---- measurement -------------------------------------------------------------------------- */
 typedef struct urt_counters {
@@ -327,6 +336,23 @@ URT_API int urt_debug_get_blas(float* nodes, int32_t* tri_index, int32_t* mesh_r
  * wall time the last preparation took; read_scene_blas copies the nodes (n_nodes x 16 floats), the index slot of every
  * leaf-order triangle and the MeshObject roots back from the GPU.  Any pointer may be NULL. */
 URT_API int urt_debug_scene_info(urt_context* ctx, int* out_n_nodes, int* out_n_tris, int* out_max_depth, float* out_prepare_ms);
+/* The last trace launch of this context (deferred frames are submitted first): which kernel instantiation ran — by the name rocprofv3
+ * prints for it, so that bench.py and the profile reducers name the kernel that really ran instead of re-deriving the dispatch logic —,
+ * its grid, its dynamic LDS and what the frame batching did (slab_frames_max < the requested batch, or slab_out_of_memory: the Result
+ * slots did not fit and the batch was halved / switched off, context.cpp ensure_slab).  No counterpart in the reference (one Dispatch
+ * per frame, RM:806-810); measurement only. */
+typedef struct urt_launch_info {
+  char kernel[96];            /* e.g. "k_sched<false, 256, 0, false, false>" (COUNT, BLOCK, FMODE, MULTI, QN: kernels.hip) */
+  int kernel_mode;            /* option "kernel_mode" the launch ran under (a degenerate dispatch runs mode 0) */
+  int front_mode;             /* kernel_mode 3 / 5: 0 one mesh, 1 BVH top walked in the object-level phase, 2 listed, 3 masked */
+  int count_stats;            /* the counting instantiation */
+  int n_blocks, block_threads, lds_bytes, waves_per_cu;
+  int n_frames, frame_group, xcd_run, tile_order, top_nodes, tlas_stack, blas_stack;
+  int lds_tables;             /* bit 0 mesh heap, 1 sphere heap + spheres, 2 single-leaf triangle records, 3 walk table */
+  int slab_frames, slab_frames_max, slab_out_of_memory;
+  int experiment;             /* 1: the library is an A/B / probe / diagnostic build (negative urt_abi_version) */
+} urt_launch_info;
+URT_API int urt_debug_launch_info(urt_context* ctx, urt_launch_info* out_info);
 URT_API int urt_debug_read_scene_blas(urt_context* ctx, float* nodes, int32_t* tri_index, int32_t* mesh_root);
 /* Scene preparation of a context keeps the triangle BVH of every MeshObject and reuses it at the next preparation when the
  * MeshObject's matrix and the positions behind its index slots are unchanged (the reference re-uploads every buffer when

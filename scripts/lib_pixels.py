@@ -2,6 +2,7 @@
 names: `URT_LIB_PATH=a.so python scripts/lib_pixels.py C3 C4` vs the same with b.so — equal hashes = bit-identical pixels of two BUILDS."""
 import hashlib, sys
 sys.path.insert(0, '.')
+import os; os.environ.setdefault("URT_ALLOW_EXPERIMENT", "1")   # a measurement tool: may load an A/B / diagnostic build (csrc/experiments.h)
 import numpy as np
 from unityraytracer_amd import Context, RayTraceMaster, scenes
 ctx = Context(0)

@@ -2,6 +2,7 @@
 kernels' time per frame of each.  Usage: python scripts/mode_ab.py [A=3] [B=5] [--configs C3 C4 ...] [--frames 32] [k=v ...] (k=v: options for mode B only)"""
 import sys, time
 sys.path.insert(0, '.')
+import os; os.environ.setdefault("URT_ALLOW_EXPERIMENT", "1")   # a measurement tool: may load an A/B / diagnostic build (csrc/experiments.h)
 import numpy as np
 from unityraytracer_amd import Context, RayTraceMaster, scenes
 

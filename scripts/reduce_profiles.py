@@ -5,7 +5,7 @@
    entry of its own launch shape up for `roofline.traffic` and the `issue` object."""
 import csv, glob, json, os, shutil, sys
 cfg = sys.argv[1] if len(sys.argv) > 1 else "C3"
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r03"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r04"
 tag = sys.argv[3] if len(sys.argv) > 3 else ""
 src = f"gpurun_out/prof_{cfg}{tag}"
 prefix = f"{rnd}_bench_{cfg.lower()}{tag}"
@@ -77,7 +77,8 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
         "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request -> doubled (MI355X_MICROARCH.md 'HBM'); WRITE_SIZE exact",
         "hbm_bytes_per_launch": hbm, "rocprof_timed_launch_ms": None if not stats or last_ns is None else last_ns / 1e6,
         "rocprof_avg_launch_ms": None if avg_ns is None else avg_ns / 1e6, "rocprof_launches": calls,
-        "bench_launch_ms": rl.get("launch_ms"), "algorithmic_bytes_per_launch": rl.get("algorithmic_bytes_per_launch"), "frac": rl.get("frac"),
+        "bench_launch_ms": rl.get("launch_ms"), "algorithmic_bytes_per_launch": (rl.get("algorithmic") or {}).get("bytes_per_launch", rl.get("algorithmic_bytes_per_launch")),
+        "algorithmic_frac_of_hbm_peak": (rl.get("algorithmic") or {}).get("frac_of_hbm_peak", rl.get("frac")),
         "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- {command} --no-cpu-baseline; the LAST launch of the timed kernel in the run"}
     # what bounds the kernel when the byte fraction saturates: issue-side figures of the same launch (separate SQ_* passes)
     need = ("SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE")
@@ -92,6 +93,7 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
             "lane_util": round(pmc["SQ_THREAD_CYCLES_VALU"] / (pmc["SQ_INSTS_VALU"] * 64.0), 4),
             "wait_frac": round(pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"], 4),
             "valu_insts_per_frame": None if not fpl else round(pmc["SQ_INSTS_VALU"] / fpl),
+            "valu_insts_per_launch": round(pmc["SQ_INSTS_VALU"]),          # bench.py's roofline: x 128 flop / its live launch time / 157.3 TFLOP/s
             "source": f"profiles/{prefix}_pmc_k_sched.json: 2 x SQ_INSTS_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE/8 cycles), SQ_THREAD_CYCLES_VALU / (SQ_INSTS_VALU x 64), SQ_WAIT_ANY / SQ_WAVE_CYCLES of the last timed launch"}
     c = allcfg["configs"].setdefault(cfg, {})
     if "by_frames_per_launch" not in c:                           # (round-2 layout: one flat entry per config)

@@ -1,5 +1,6 @@
 import sys, ctypes as C
 sys.path.insert(0, '.')
+import os; os.environ.setdefault("URT_ALLOW_EXPERIMENT", "1")   # a measurement tool: may load an A/B / diagnostic build (csrc/experiments.h)
 import numpy as np
 from unityraytracer_amd import Context, RayTraceMaster, scenes, _lib
 ctx = Context(0)

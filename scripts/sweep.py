@@ -111,6 +111,7 @@ def main():
             env = dict(os.environ)
             if lib != "default":
                 env["URT_LIB_PATH"] = os.path.abspath(lib)
+                env["URT_ALLOW_EXPERIMENT"] = "1"              # A/B builds report a negative ABI version and are refused otherwise (csrc/experiments.h)
             out = subprocess.run(child, env=env, capture_output=True, text=True, cwd=ROOT)
             for line in out.stdout.splitlines():
                 print(f"{os.path.basename(lib):24s} {line}", flush=True)

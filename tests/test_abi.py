@@ -33,7 +33,31 @@ def test_library_exports_every_declared_symbol(built_library):
     lib = C.CDLL(built_library)
     for name in header_symbols():
         assert hasattr(lib, name), f"{name} is declared in include/urt.h but not exported"
-    assert _lib.load().urt_abi_version() == 3
+    assert _lib.load().urt_abi_version() == 4          # positive: the product build (negative = an experiment build, below)
+
+
+def test_experiment_switches_are_quarantined():
+    """Every A/B / probe / diagnostic compile-time switch of csrc/ sits behind csrc/experiments.h: a translation unit that sees one
+    without -DURT_EXPERIMENT does not compile, an experiment build reports a negative ABI version, and _lib.load() refuses such a
+    library unless the caller opts in (URT_ALLOW_EXPERIMENT=1: scripts/ only)."""
+    csrc = os.path.join(ROOT, "unityraytracer_amd", "csrc")
+    guard = open(os.path.join(csrc, "experiments.h")).read()
+    used = set()
+    for f in os.listdir(csrc):
+        if f != "experiments.h":
+            used |= set(re.findall(r"#\s*if(?:n?def|\s+defined\(?)\s*(URT_[A-Z0-9_]+)", open(os.path.join(csrc, f)).read()))
+    used -= {"URT_EXPERIMENT"}
+    assert used, "no switches found: the scan is broken"
+    for name in used:
+        assert f"defined({name})" in guard, f"{name} is a compile-time switch that csrc/experiments.h does not guard"
+    for src in ("kernels.hip", "context.cpp", "blas_builder.cpp"):
+        head = open(os.path.join(csrc, src)).read()
+        first_include = re.search(r'^#include\s+[<"]([^">]+)[">]', head, re.M).group(1)
+        assert first_include == "experiments.h", (src, first_include)
+    assert "URT_ABI_SIGN * " in open(os.path.join(csrc, "context.cpp")).read()
+    # the loader's side: a library whose urt_abi_version() is negative is refused (checked on the logic, no second build needed)
+    text = open(os.path.join(ROOT, "unityraytracer_amd", "_lib.py")).read()
+    assert "urt_abi_version() < 0" in text and "URT_ALLOW_EXPERIMENT" in text
 
 
 def test_layout_strides_match_reference():

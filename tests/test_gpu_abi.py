@@ -210,3 +210,54 @@ def test_two_hosts_interleaved_on_one_context(gpu_ctx):
     got_a, got_b = ma._converged.GetPixels(), mb._converged.GetPixels()
     ma.OnDisable(); mb.OnDisable()
     assert bits_equal(got_a, want_a) and bits_equal(got_b, want_b)
+
+
+def test_rgb_strip_pack_and_unpack(gpu_ctx):
+    """urt_texture_pack_rows_rgb / urt_texture_unpack_rows_rgb: three channels per pixel travel, the de-interleave writes the alpha it is
+    given; ragged last strip; the packed size is 12 B per pixel of the rank's padded strips."""
+    import ctypes as C
+    import torch
+    from unityraytracer_amd import RenderTexture, strips
+    w, h, world = 40, 52, 3                                   # 7 group rows, the last with 4 pixel rows
+    rng = np.random.default_rng(3)
+    img = rng.random((h, w, 4), dtype=np.float32)
+    src = RenderTexture(gpu_ctx, w, h)
+    src.SetPixels(img)
+    dst = RenderTexture(gpu_ctx, w, h)
+    dst.SetPixels(np.zeros_like(img))
+    for rank in range(world):
+        nb = C.c_uint64()
+        gpu_ctx.check(gpu_ctx.lib.urt_texture_pack_rows_rgb(gpu_ctx._h, src.handle, rank, world, None, C.byref(nb)))
+        assert nb.value == strips.n_strips(h, rank, world) * 8 * w * 12
+        buf = torch.full((strips.packed_rows(h, world) * w * 3,), -1.0, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        src.pack_rows(rank, world, buf.data_ptr(), rgb=True)
+        dst.unpack_rows_rgb(rank, world, buf.data_ptr(), 0.25)
+        gpu_ctx.synchronize()
+        host = buf.cpu().numpy().reshape(-1, w, 3)
+        for j, (y0, y1) in enumerate(strips.strip_row_ranges(h, rank, world)):
+            assert np.array_equal(host[8 * j: 8 * j + (y1 - y0)], img[y0:y1, :, :3])
+            assert (host[8 * j + (y1 - y0): 8 * j + 8] == 0).all()          # rows beyond the image are zero-filled
+    got = dst.GetPixels()
+    assert np.array_equal(got[..., :3], img[..., :3]) and (got[..., 3] == 0.25).all()
+    src.Release(); dst.Release()
+
+
+def test_launch_info_names_the_kernel_that_ran(gpu_ctx):
+    from unityraytracer_amd import RayTraceMaster, scenes
+    sc = scenes.mixed_test_scene(96, 64)
+    m = RayTraceMaster(gpu_ctx, sc)
+    try:
+        for mode, name in ((0, "k_mega<false>"), (2, "k_persist<false>"), (3, "k_sched<false, 256, ")):
+            gpu_ctx.set_option("kernel_mode", mode)
+            m.OnRenderImage()
+            info = gpu_ctx.launch_info()
+            assert info["kernel"].startswith(name) and info["kernel_mode"] == mode and info["experiment"] == 0, info
+            assert info["n_blocks"] > 0 and info["lds_bytes"] > 0
+        gpu_ctx.set_option("count_stats", 1)
+        m.OnRenderImage()
+        assert gpu_ctx.launch_info()["kernel"].startswith("k_sched<true, 256, ")
+    finally:
+        gpu_ctx.set_option("count_stats", 0)
+        gpu_ctx.set_option("kernel_mode", 3)
+        m.OnDisable()

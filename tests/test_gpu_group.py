@@ -115,3 +115,28 @@ def test_group_present_after_gather_is_ordered(gpu_ctx, fpl):
         assert bits_equal(full2.GetPixels(), flat)
         full.Release(); dest.Release(); full2.Release()
         m.OnDisable(); m2.OnDisable()
+
+
+@pytest.mark.parametrize("fpl", [0, 1])
+def test_group_blit_of_a_gather_source_keeps_program_order(gpu_ctx, fpl):
+    """gather(_converged -> full), then Blit(_converged, snap), then two more frames: `snap` must hold the mean after the frame the
+    blit followed — a blit that reads a gather's SOURCE is ordered by the ranks' own deferred operations and must not be queued
+    behind the late unpack, where it would run after frames dispatched later (group.cpp urt_group_blit)."""
+    from unityraytracer_amd import Graphics
+    sc = scenes.mixed_test_scene(176, 120)
+    n = 5
+    ref = single_context_frames(gpu_ctx, sc, n)
+    with DeviceGroup([0, 0, 0]) as g:
+        g.set_option("frames_per_launch", fpl)
+        m = RayTraceMaster(g, sc)
+        full = RenderTexture(g, sc.width, sc.height)
+        snap = RenderTexture(g, sc.width, sc.height)
+        for i in range(n):
+            m.OnRenderImage()
+            g.gather(m._converged, full)
+            if i == 2:
+                Graphics.Blit(m._converged, snap)          # every rank copies ITS strips of the mean after frame 2
+        g.gather(snap, full)                               # bring the snapshot's strips together
+        assert bits_equal(full.GetPixels(), ref[2]), fpl
+        full.Release(); snap.Release()
+        m.OnDisable()

@@ -123,3 +123,56 @@ def test_one_rank_nccl_gather_smoke(gpu_ctx, tmp_path):
     want = m._converged.GetPixels()
     m.OnDisable()
     assert np.array_equal(np.load(out).view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.timeout(900)
+def test_bench_strong_scaling_two_ranks_rgb_gather(tmp_path):
+    """`python bench.py --scaling strong --config C4 --gpus 2`: the FIXED 3840x2160 frame of BASELINE config 4 divided among two ranks
+    (sharing this box's card, gloo rehearsal), the frame-end gather moving RGB only (12 B per pixel; rank 0 writes the alpha of the
+    running mean itself); rank 0 verifies all four channels of the gathered image against a single-rank render bit for bit."""
+    import json
+    import subprocess
+    env = dict(os.environ, URT_DIST_BACKEND="gloo", URT_BENCH_VERIFY="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1", "--config", "C4",
+                        "--scaling", "strong", "--clock-warmup-ms", "0", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "[verify] gathered 2-rank frame == single-rank frame: True" in r.stderr, r.stderr[-3000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert j["scaling"] == "strong" and j["n_gpus"] == 2 and j["config"]["frame"] == [3840, 2160] and j["config"]["pixels_per_gpu"] == 3840 * 2160 // 2
+    assert "RGB, 12 B" in j["config"]["partition"]
+
+
+@pytest.mark.timeout(900)
+def test_bench_rgba_gather_still_available():
+    import subprocess
+    env = dict(os.environ, URT_DIST_BACKEND="gloo", URT_BENCH_VERIFY="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--config", "C2", "--gather-rgb", "0",
+                        "--gather-every", "2", "--clock-warmup-ms", "0", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "[verify] gathered 2-rank frame == single-rank frame: True" in r.stderr, r.stderr[-3000:]
+
+
+@pytest.mark.timeout(900)
+def test_the_drivers_bench_command_verified_against_the_oracle():
+    """The driver's own command, `python bench.py --gpus 1 --steps 20 --warmup 5`, with URT_BENCH_VERIFY=1: after the timed region the
+    presented image (`destination`, and `_converged`) must equal the oracle's running mean of the same 25 frames bit for bit; the line
+    must name the kernel the library launched and carry a roofline fraction that cannot exceed 1."""
+    import json
+    import subprocess
+    env = dict(os.environ, URT_BENCH_VERIFY="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "URT_LIB_PATH", "URT_ALLOW_EXPERIMENT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5"], env=env, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "== the oracle's running mean: True" in r.stderr, r.stderr[-3000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert j["verified_against_oracle"] is True and j["n_gpus"] == 1 and j["steps"] == 20 and j["scaling"] == "weak"
+    rl = j["roofline"]
+    assert rl["kernel"] == "k_sched<false, 256, 0, false, false>" and rl["frames_per_launch"] == 20
+    assert rl["frac"] is None or 0 < rl["frac"] <= 1.0, rl
+    assert rl["algorithmic"]["bytes_per_launch"] > 0 and "saturated" in rl["algorithmic"]
+    assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["value"] > 0

@@ -53,3 +53,23 @@ def test_two_rank_strips_gather_equals_single_frame(tmp_path):
     full = o.render(mode=1)
     got = np.load(out)
     assert np.array_equal(got.view(np.uint32), full.view(np.uint32))
+
+
+def test_running_mean_alpha_is_a_function_of_the_sample_sequence():
+    """The RGB gather (urt_texture_pack_rows_rgb / unpack_rows_rgb) leaves the alpha channel of `_converged` at home: AdditionShader's
+    source alpha is a = 1 / (_Sample + 1) and is blended like the colours (AS:39-41), so every pixel holds the same value after sample
+    n.  strips.running_mean_alpha must be exactly what the oracle's blend leaves in the alpha channel, whatever the colours."""
+    from oracle import pyoracle
+    from unityraytracer_amd import strips
+    rng = np.random.default_rng(7)
+    conv = np.zeros((3, 5, 4), np.float32)
+    for n in range(70):
+        frame = rng.random((3, 5, 4), dtype=np.float32) * 3.0
+        frame[..., 3] = 1.0                                   # CSMain writes alpha 1 (RS:468) — the blend does not read it
+        conv = pyoracle.accumulate(frame, conv, n)
+        w = np.float32(strips.running_mean_alpha(range(n + 1)))
+        assert np.all(conv[..., 3].view(np.uint32) == w.view(np.uint32)), n
+    # a reset (sample 0 blends with alpha 1) restarts the sequence, whatever came before
+    conv = pyoracle.accumulate(frame, conv, 0)
+    conv = pyoracle.accumulate(frame, conv, 1)
+    assert np.all(conv[..., 3] == np.float32(strips.running_mean_alpha([0, 1])))

@@ -21,8 +21,8 @@ ABI_SYMBOLS = [
     "urt_texture_create_external", "urt_texture_set_pixels", "urt_texture_get_pixels", "urt_texture_get_info", "urt_texture_release",
     "urt_shader_set_buffer", "urt_shader_set_texture", "urt_shader_set_matrix", "urt_shader_set_vector", "urt_shader_set_float",
     "urt_shader_set_int", "urt_shader_dispatch", "urt_shader_dispatch_rows", "urt_blit_add", "urt_blit", "urt_texture_pack_rows",
-    "urt_texture_unpack_rows", "urt_texture_unpack_rows_on", "urt_set_option", "urt_get_counters", "urt_reset_counters", "urt_debug_build_blas", "urt_debug_get_blas", "urt_debug_blas_cache_stats",
-    "urt_debug_scene_info", "urt_debug_read_scene_blas", "urt_debug_serve_stats", "urt_debug_refit_stats", "urt_debug_build_walk_table", "urt_host_compute_normals", "urt_host_mesh_leaf_bounds", "urt_host_sphere_leaf_bounds", "urt_host_object_bvh_length",
+    "urt_texture_unpack_rows", "urt_texture_unpack_rows_on", "urt_texture_pack_rows_rgb", "urt_texture_unpack_rows_rgb", "urt_set_option", "urt_get_counters", "urt_reset_counters", "urt_debug_build_blas", "urt_debug_get_blas", "urt_debug_blas_cache_stats",
+    "urt_debug_scene_info", "urt_debug_launch_info", "urt_debug_read_scene_blas", "urt_debug_serve_stats", "urt_debug_refit_stats", "urt_debug_build_walk_table", "urt_host_compute_normals", "urt_host_mesh_leaf_bounds", "urt_host_sphere_leaf_bounds", "urt_host_object_bvh_length",
     "urt_host_build_object_bvh", "urt_host_build_object_bvh_pairing", "urt_host_last_error", "urt_host_load_hdr", "urt_host_write_pfm", "urt_host_write_png",
     "urt_host_resize_rgba", "urt_host_io_last_error", "urt_host_log", "urt_host_log_scene_counts", "urt_host_log_tree_report", "urt_host_dump_bvh", "urt_host_dump_normals",
     "urt_host_debug_last_error",
@@ -43,6 +43,19 @@ class Counters(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+class LaunchInfo(C.Structure):
+    """urt_launch_info (include/urt.h): the last trace launch of a context."""
+    _fields_ = [("kernel", C.c_char * 96)] + [(n, C.c_int) for n in (
+        "kernel_mode", "front_mode", "count_stats", "n_blocks", "block_threads", "lds_bytes", "waves_per_cu", "n_frames", "frame_group",
+        "xcd_run", "tile_order", "top_nodes", "tlas_stack", "blas_stack", "lds_tables", "slab_frames", "slab_frames_max",
+        "slab_out_of_memory", "experiment")]
+
+    def as_dict(self):
+        d = {n: getattr(self, n) for n, _ in self._fields_}
+        d["kernel"] = self.kernel.decode()
+        return d
+
+
 class UrtError(RuntimeError):
     def __init__(self, code: int, message: str):
         super().__init__(f"URT_ERR_{ERROR_NAMES.get(code, code)}: {message}")
@@ -61,6 +74,12 @@ def load():
         raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the HIP path.")
     lib = C.CDLL(LIB_PATH)
+    lib.urt_abi_version.argtypes, lib.urt_abi_version.restype = [], C.c_int
+    if lib.urt_abi_version() < 0 and os.environ.get("URT_ALLOW_EXPERIMENT") != "1":
+        # an A/B, probe or diagnostic BUILD (csrc/experiments.h: -DURT_STAMPS, -DURT_PROBE_NOSTORE, ...): never the product.  Only the
+        # measurement scripts under scripts/ opt in; tests, bench.py and the smoke must not run on one by accident (URT_LIB_PATH).
+        raise ImportError(f"{LIB_PATH} is an experiment build (urt_abi_version() = {lib.urt_abi_version()}): refused. "
+                          "Set URT_ALLOW_EXPERIMENT=1 to load it on purpose (scripts/ only).")
     vp, i, f, u64 = C.c_void_p, C.c_int, C.c_float, C.c_uint64
     pi, pf = C.POINTER(C.c_int), C.POINTER(C.c_float)
     protos = {
@@ -95,6 +114,8 @@ def load():
         "urt_texture_pack_rows": ([vp, u64, i, i, vp, C.POINTER(u64)], i),
         "urt_texture_unpack_rows": ([vp, u64, i, i, vp], i),
         "urt_texture_unpack_rows_on": ([vp, u64, i, i, vp, vp], i),
+        "urt_texture_pack_rows_rgb": ([vp, u64, i, i, vp, C.POINTER(u64)], i),
+        "urt_texture_unpack_rows_rgb": ([vp, u64, i, i, vp, f, vp], i),
         "urt_set_option": ([vp, C.c_char_p, i], i),
         "urt_get_counters": ([vp, C.POINTER(Counters)], i),
         "urt_reset_counters": ([vp], i),
@@ -102,6 +123,7 @@ def load():
         "urt_debug_get_blas": ([vp, vp, vp, vp], i),
         "urt_debug_blas_cache_stats": ([vp, vp, vp], i),
         "urt_debug_scene_info": ([vp, pi, pi, pi, pf], i),
+        "urt_debug_launch_info": ([vp, C.POINTER(LaunchInfo)], i),
         "urt_debug_serve_stats": ([vp, vp], i),
         "urt_debug_refit_stats": ([vp, vp, vp], i),
         "urt_debug_build_walk_table": ([vp, i, i, vp, vp, vp, i, pi], i),

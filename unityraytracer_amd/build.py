@@ -34,9 +34,11 @@ def build_variant(out: str, defines, verbose: bool = False) -> str:
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     objdir = os.path.join(_HERE, "build", os.path.splitext(os.path.basename(out))[0])
     os.makedirs(objdir, exist_ok=True)
-    cflags = [f for f in HIPCC_FLAGS if f != "-shared"] + list(defines)
+    # every variant is an EXPERIMENT build: negative urt_abi_version, refused by _lib.load() unless URT_ALLOW_EXPERIMENT=1 (csrc/experiments.h)
+    cflags = [f for f in HIPCC_FLAGS if f != "-shared"] + ["-DURT_EXPERIMENT"] + [d for d in defines if d != "-DURT_EXPERIMENT"]
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     base = os.path.join(_HERE, "build")
+    build_library()                                          # the objects shared with the product must be current (they are reused below)
 
     def run(cmd):
         if verbose:
@@ -66,7 +68,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     hdrs = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")] + \
         [os.path.join(_ROOT, "include", h) for h in os.listdir(os.path.join(_ROOT, "include"))]
-    if not force and _newer(LIB, srcs + hdrs):
+    if not force and _newer(LIB, srcs + hdrs + [os.path.abspath(__file__)]):     # (the flags live in this file)
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     objdir = os.path.join(_HERE, "build")

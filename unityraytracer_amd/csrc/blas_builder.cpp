@@ -12,6 +12,7 @@
 // triangle records (v0, e1 = v1-v0, e2 = v2-v0, index slot, mesh id) and leaf-ordered vertex normals.
 // Child boxes are padded by 2^-16 * (largest |coordinate| of the mesh) so that the slab test can never
 // cull a triangle that the float32 Moller-Trumbore test would accept (DESIGN.md "BLAS traversal").
+#include "experiments.h"
 #include "blas_builder.h"
 
 #include <algorithm>

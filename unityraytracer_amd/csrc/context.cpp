@@ -6,6 +6,7 @@
 //   ComputeShader   -> the uniform/binding table in urt_context + dispatch of the HIP kernels
 //   Graphics.Blit   -> urt_blit / urt_blit_add
 // There is deliberately no CPU path: without a HIP device context creation fails.
+#include "experiments.h"
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -191,6 +192,7 @@ struct urt_context {
   unsigned int* d_trip_flag = nullptr;      // its device address
   int opt_watchdog_cap = 0;                 // test hook: scheduler trips per wave (0 = auto, scaled with the launch)
   int slab_frames_max = 0;                  // largest batch the Result slab could be allocated for (after out-of-memory retries)
+  urt_launch_info last_launch{};            // the last trace launch of this context (urt_debug_launch_info)
   size_t slab_oom_stride = 0;               // image size (pixels) for which not even two slots could be allocated
 };
 
@@ -241,6 +243,7 @@ void free_scene(urt_context* ctx) {
   ctx->refit = urt_context::RefitAux{};
   ctx->qbuf = nullptr; ctx->cbuf = nullptr;
   ctx->cap_materials = ctx->cap_mesh_tlas = ctx->cap_sphere_tlas = ctx->cap_sphere_pr = 0;
+  ctx->slab_oom_stride = 0;                                // device memory came back: the next batch may try the Result slots again
 }
 
 template <typename T>
@@ -772,7 +775,10 @@ int detach_from_slab(urt_context* ctx, Texture& t) {
 int ensure_slab(urt_context* ctx, urt_handle h, Texture& t, int frames) {
   size_t stride = (size_t)t.w * (size_t)t.h;
   if (ctx->slab && ctx->slab_tex == h && ctx->slab_stride == stride && ctx->slab_frames >= frames) return URT_OK;
-  if (!ctx->slab && ctx->slab_oom_stride == stride) return URT_OK;   // two slots of this size did not fit last time: not tried per frame
+  // two slots of this size did not fit last time: not tried per frame — but again after a release in this context (free_scene,
+  // urt_texture_release clear the mark) and every 256th dispatch (another context on the card may have given memory back);
+  // urt_debug_launch_info reports the degradation (slab_frames_max, slab_out_of_memory)
+  if (!ctx->slab && ctx->slab_oom_stride == stride && (ctx->dispatches & 255u) != 0) return URT_OK;
   if (ctx->slab_tex) {                                   // somebody's current contents may live in the old slab
     auto it = ctx->textures.find(ctx->slab_tex);
     if (it != ctx->textures.end()) { int rc = detach_from_slab(ctx, it->second); if (rc) return rc; }
@@ -896,6 +902,22 @@ int configure_sched(urt_context* ctx, const DevScene& S, FrameParams& P, bool to
   return mode;
 }
 
+// What urt_debug_launch_info reports: taken right after a launcher of kernels.hip returned (one host thread per context)
+void record_launch(urt_context* ctx, int kernel_mode, int front_mode, const FrameParams& P, bool count, int waves_per_cu) {
+  urt_launch_info& I = ctx->last_launch;
+  const TraceLaunchRecord& R = last_trace_launch();
+  std::memset(&I, 0, sizeof I);
+  std::snprintf(I.kernel, sizeof I.kernel, "%s", R.kernel);
+  I.kernel_mode = kernel_mode; I.front_mode = front_mode; I.count_stats = count ? 1 : 0;
+  I.n_blocks = R.n_blocks; I.block_threads = R.block_threads; I.lds_bytes = R.lds_bytes;
+  I.n_frames = P.n_frames; I.frame_group = P.frame_group; I.xcd_run = P.xcd_run; I.tile_order = P.tile_order;
+  I.top_nodes = P.top_nodes; I.waves_per_cu = waves_per_cu;
+  I.tlas_stack = P.tlas_stack; I.blas_stack = P.blas_stack;
+  I.lds_tables = (P.lds_mesh ? 1 : 0) | (P.lds_sphere ? 2 : 0) | (P.lds_small ? 4 : 0) | (P.walk_f4 > 0 ? 8 : 0);
+  I.slab_frames = ctx->slab_frames; I.slab_frames_max = ctx->slab_frames_max; I.slab_out_of_memory = ctx->slab_oom_stride != 0 ? 1 : 0;
+  I.experiment = URT_ABI_SIGN < 0 ? 1 : 0;
+}
+
 // Launch the phase-scheduled trace kernel for P.n_frames frames (uniforms T) into result + f * P.frame_stride.
 static constexpr int kAutoFrames = 64;     // frames per launch when "frames_per_launch" is 0 (auto) on the library's own stream
 
@@ -946,6 +968,7 @@ int launch_sched_frames(urt_context* ctx, const DevScene& S, const FrameParams& 
   }
   ctx->launches++;
   if (le != hipSuccess) return fail(ctx, URT_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(le));
+  record_launch(ctx, P.serve ? 5 : 3, front_mode, P, count, wpc);
   return URT_OK;
 }
 
@@ -1014,7 +1037,8 @@ int flush_pending(urt_context* ctx) {
       const float4* img = op.tex == B.tex ? ctx->slab + (size_t)op.frame * ctx->slab_stride : t->dev;
       int group_rows = (t->h + 7) / 8;
       int n_strips = op.first_row < group_rows ? (group_rows - op.first_row + op.row_stride - 1) / op.row_stride : 0;
-      hipError_t e = launch_pack_rows(const_cast<float4*>(img), (float4*)op.dense, t->w, t->h, op.first_row, op.row_stride, n_strips, true, ctx->stream);
+      hipError_t e = op.sample != 0.0f ? launch_pack_rows_rgb(const_cast<float4*>(img), (float*)op.dense, t->w, t->h, op.first_row, op.row_stride, n_strips, true, 0.0f, ctx->stream)
+                                       : launch_pack_rows(const_cast<float4*>(img), (float4*)op.dense, t->w, t->h, op.first_row, op.row_stride, n_strips, true, ctx->stream);
       if (e != hipSuccess) return fail(ctx, URT_ERR_HIP, std::string("deferred pack_rows: ") + hipGetErrorString(e));
       i++;
     }
@@ -1197,6 +1221,7 @@ int do_dispatch(urt_context* ctx, int kernel, int gx, int gy, int gz, int first_
     }
     ctx->launches++;
     if (le != hipSuccess) return fail(ctx, URT_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(le));
+    record_launch(ctx, mode, 0, P, count, ctx->opt_waves_per_cu);
   }
   // remember what has written the image (see Texture)
   if (res->n_regions == 0) { res->n_regions = 1; std::memcpy(res->rg, region, sizeof region); }
@@ -1208,7 +1233,7 @@ int do_dispatch(urt_context* ctx, int kernel, int gx, int gy, int gz, int first_
 
 extern "C" {
 
-int urt_abi_version(void) { return 3; }
+int urt_abi_version(void) { return URT_ABI_SIGN * 4; }   // negative: an A/B / probe / diagnostic build (csrc/experiments.h), refused by loaders that did not opt in
 
 int urt_device_count(int* out_count) {
   if (!out_count) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "out_count is NULL");
@@ -1445,6 +1470,7 @@ int urt_texture_release(urt_context* ctx, urt_handle texture) {
   { int rc = flush_pending(ctx); if (rc) return rc; }
   URT_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (!it->second.external && it->second.own) (void)hipFree(it->second.own);
+  ctx->slab_oom_stride = 0;                                // device memory came back: the next batch may try the Result slots again
   if (ctx->slab_tex == texture) ctx->slab_tex = 0;
   if (ctx->t_sky == texture) ctx->t_sky = 0;
   if (ctx->t_result == texture) ctx->t_result = 0;
@@ -1575,26 +1601,27 @@ int urt_blit(urt_context* ctx, urt_handle src, urt_handle dst) {
 }
 
 static int pack_impl(urt_context* ctx, urt_handle texture, int first_group_row, int row_stride, void* dense, bool to_dense,
-                     uint64_t* out_bytes) {
+                     uint64_t* out_bytes, bool rgb = false, float alpha = 0.0f) {
   if (!ctx) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "ctx is NULL");
   Texture* t = find_texture(ctx, texture);
   if (!t) return fail(ctx, URT_ERR_INVALID_HANDLE, "unknown texture handle");
   if (first_group_row < 0 || row_stride < 1) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "bad strip arguments");
   int group_rows = (t->h + 7) / 8;
   int n_strips = first_group_row < group_rows ? (group_rows - first_group_row + row_stride - 1) / row_stride : 0;
-  if (out_bytes) *out_bytes = (uint64_t)n_strips * 8u * (uint64_t)t->w * sizeof(float4);
+  if (out_bytes) *out_bytes = (uint64_t)n_strips * 8u * (uint64_t)t->w * (rgb ? 3 * sizeof(float) : sizeof(float4));
   if (!dense) return URT_OK;   // size query
   URT_HIP(ctx, hipSetDevice(ctx->device));
   URT_GUARD_BEGIN
   urt_context::Pending& B = ctx->pend;
   if (to_dense && B.n > 0) {     // reads an image that deferred work is still going to write: deferred with it, in order
-    B.ops.push_back(urt_context::PostOp{1, B.n - 1, texture, 0, 0.0f, first_group_row, row_stride, dense});
+    B.ops.push_back(urt_context::PostOp{1, B.n - 1, texture, 0, rgb ? 1.0f : 0.0f, first_group_row, row_stride, dense});   // (sample != 0: the RGB form)
     return URT_OK;
   }
   { int rc = flush_pending(ctx); if (rc) return rc; }
   if (!to_dense) t->other_writes = true;
   URT_GUARD_END(ctx)
-  URT_HIP(ctx, launch_pack_rows(t->dev, (float4*)dense, t->w, t->h, first_group_row, row_stride, n_strips, to_dense, ctx->stream));
+  if (rgb) URT_HIP(ctx, launch_pack_rows_rgb(t->dev, (float*)dense, t->w, t->h, first_group_row, row_stride, n_strips, to_dense, alpha, ctx->stream));
+  else URT_HIP(ctx, launch_pack_rows(t->dev, (float4*)dense, t->w, t->h, first_group_row, row_stride, n_strips, to_dense, ctx->stream));
   return URT_OK;
 }
 
@@ -1603,8 +1630,8 @@ int urt_texture_pack_rows(urt_context* ctx, urt_handle texture, int first_group_
   return pack_impl(ctx, texture, first_group_row, row_stride, device_dst, true, out_bytes);
 }
 
-int urt_texture_unpack_rows_on(urt_context* ctx, urt_handle texture, int first_group_row, int row_stride, const void* device_src,
-                               void* hip_stream) {
+static int unpack_on_impl(urt_context* ctx, urt_handle texture, int first_group_row, int row_stride, const void* device_src,
+                          void* hip_stream, bool rgb, float alpha) {
   if (!ctx) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "ctx is NULL");
   if (!device_src || !hip_stream) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "device_src / hip_stream is NULL");
   Texture* t = find_texture(ctx, texture);
@@ -1620,9 +1647,28 @@ int urt_texture_unpack_rows_on(urt_context* ctx, urt_handle texture, int first_g
   int n_strips = first_group_row < group_rows ? (group_rows - first_group_row + row_stride - 1) / row_stride : 0;
   t->other_writes = true;
   URT_HIP(ctx, hipSetDevice(ctx->device));
-  URT_HIP(ctx, launch_pack_rows(t->dev, (float4*)const_cast<void*>(device_src), t->w, t->h, first_group_row, row_stride, n_strips, false,
-                                (hipStream_t)hip_stream));
+  if (rgb) URT_HIP(ctx, launch_pack_rows_rgb(t->dev, (float*)const_cast<void*>(device_src), t->w, t->h, first_group_row, row_stride, n_strips, false,
+                                            alpha, (hipStream_t)hip_stream));
+  else URT_HIP(ctx, launch_pack_rows(t->dev, (float4*)const_cast<void*>(device_src), t->w, t->h, first_group_row, row_stride, n_strips, false,
+                                     (hipStream_t)hip_stream));
   return URT_OK;
+}
+
+int urt_texture_unpack_rows_on(urt_context* ctx, urt_handle texture, int first_group_row, int row_stride, const void* device_src,
+                               void* hip_stream) {
+  return unpack_on_impl(ctx, texture, first_group_row, row_stride, device_src, hip_stream, false, 0.0f);
+}
+
+int urt_texture_pack_rows_rgb(urt_context* ctx, urt_handle texture, int first_group_row, int row_stride, void* device_dst,
+                              uint64_t* out_bytes) {
+  return pack_impl(ctx, texture, first_group_row, row_stride, device_dst, true, out_bytes, true);
+}
+
+int urt_texture_unpack_rows_rgb(urt_context* ctx, urt_handle texture, int first_group_row, int row_stride, const void* device_src,
+                                float alpha, void* hip_stream) {
+  if (ctx && !device_src) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "device_src is NULL");
+  if (hip_stream) return unpack_on_impl(ctx, texture, first_group_row, row_stride, device_src, hip_stream, true, alpha);
+  return pack_impl(ctx, texture, first_group_row, row_stride, const_cast<void*>(device_src), false, nullptr, true, alpha);
 }
 
 int urt_texture_unpack_rows(urt_context* ctx, urt_handle texture, int first_group_row, int row_stride, const void* device_src) {
@@ -1850,6 +1896,14 @@ int urt_debug_refit_stats(urt_context* ctx, uint64_t* out_refitted_meshes, uint6
   if (!ctx) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "ctx is NULL");
   if (out_refitted_meshes) *out_refitted_meshes = ctx->refitted_meshes;
   if (out_incremental_preparations) *out_incremental_preparations = ctx->incremental_preps;
+  return URT_OK;
+}
+
+int urt_debug_launch_info(urt_context* ctx, urt_launch_info* out) {
+  if (!ctx || !out) return URT_ERR_INVALID_ARGUMENT;
+  int rc = flush_pending(ctx); if (rc) return rc;          // "the last launch" includes the frames still deferred
+  *out = ctx->last_launch;
+  out->slab_frames = ctx->slab_frames; out->slab_frames_max = ctx->slab_frames_max; out->slab_out_of_memory = ctx->slab_oom_stride != 0 ? 1 : 0;
   return URT_OK;
 }
 

@@ -155,6 +155,15 @@ bool touches_pending(const urt_group* g, urt_handle a, urt_handle b) {
   return false;
 }
 
+// is one of these images WRITTEN by work that is still queued here — a gather's late unpack (its dst) or a blit queued behind one?
+// Only such images force a blit into the queue: what reads or writes a gather's SRC is ordered by the rank contexts' own deferred
+// operations (the pack was queued there in program order), and queuing it would run it after frames dispatched later.
+bool written_by_pending(const urt_group* g, urt_handle a, urt_handle b) {
+  for (const urt_group::PendingGather& op : g->pending)
+    if (op.dst == a || (b && op.dst == b)) return true;
+  return false;
+}
+
 }  // namespace
 
 extern "C" {
@@ -268,7 +277,7 @@ int urt_group_blit_add(urt_group* g, urt_handle src, urt_handle dst, float sampl
   FORWARD(g, urt_blit_add(c, src, dst, sample));
 }
 int urt_group_blit(urt_group* g, urt_handle src, urt_handle dst) {
-  if (g && touches_pending(g, src, dst)) {
+  if (g && written_by_pending(g, src, dst)) {
     // the present of a gathered image (gather(_converged -> full); Blit(full, destination), RM:819): queued with the gathers, it
     // runs right after the unpack it depends on — the ranks keep batching their frames
     g->pending.push_back(urt_group::PendingGather{1, src, dst, 0});

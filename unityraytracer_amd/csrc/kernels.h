@@ -5,6 +5,12 @@
 
 namespace urtd {
 
+// the last trace launch made through the launchers below (process-wide, written on the launching host thread): the kernel instantiation by
+// the name rocprofv3 prints for it, its grid and its dynamic LDS — what urt_debug_launch_info reports, so that tools name the kernel that
+// really ran instead of re-deriving the dispatch logic
+struct TraceLaunchRecord { char kernel[96]; int n_blocks, block_threads, lds_bytes; };
+const TraceLaunchRecord& last_trace_launch();
+
 // mode 0: whole CSMain per thread (RS:431-469)
 hipError_t launch_mega(const DevScene& S, const FrameParams& P, float4* result, DevCounters* ctr, bool count, hipStream_t st);
 // mode 1: generate + one launch per bounce over compacted path queues
@@ -39,5 +45,9 @@ hipError_t launch_blit_add(const float4* src, float4* dst, size_t n_pixels, floa
 // strips <-> dense buffer
 hipError_t launch_pack_rows(float4* img, float4* dense, int width, int height, int first_group_row, int row_stride,
                             int n_strips, bool to_dense, hipStream_t st);
+
+// the same with three channels per pixel (12 B, RGB); unpacking writes `alpha` into the fourth
+hipError_t launch_pack_rows_rgb(float4* img, float* dense, int width, int height, int first_group_row, int row_stride,
+                                int n_strips, bool to_dense, float alpha, hipStream_t st);
 
 }  // namespace urtd

@@ -22,8 +22,11 @@
 //    measured alternatives and cross-checks.
 // Arithmetic is the normative float32 of include/urt_math.h, compiled with -ffp-contract=off; results
 // are bit-identical to the scalar restatement in oracle/ (tests/test_gpu_parity.py).
+#include "experiments.h"    // first: it looks at the -D switches before any default below is defined
 #include <hip/hip_runtime.h>
+#include <stdarg.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #include "../../include/urt_math.h"
 #include "urt_device.h"
@@ -2302,6 +2305,29 @@ __global__ __launch_bounds__(256) void k_pack_rows(const float4* __restrict__ im
   }
 }
 
+// The same strips with THREE channels per pixel (12 B): the frame-end gather of a running mean need not move its alpha channel — after
+// sample n it is the same value in every pixel, a function of the sample sequence alone (AS:40: the fragment's alpha is a itself and is
+// blended like the colours) — so the root writes `alpha` itself when it de-interleaves.  A quarter of the gather's bytes less.
+__global__ __launch_bounds__(256) void k_pack_rows_rgb(const float4* __restrict__ img, float* __restrict__ dense, int width, int height,
+                                                       int first_group_row, int row_stride, int n_strips, int to_dense, float alpha) {
+  size_t per_strip = (size_t)width * 8;
+  size_t n = per_strip * (size_t)n_strips;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    int j = (int)(i / per_strip);
+    size_t r = i - (size_t)j * per_strip;
+    int row = (first_group_row + j * row_stride) * 8 + (int)(r / (size_t)width);
+    int col = (int)(r % (size_t)width);
+    float* d = dense + 3 * i;
+    if (row < height) {
+      size_t at = (size_t)row * width + col;
+      if (to_dense) { float4 v = img[at]; d[0] = v.x; d[1] = v.y; d[2] = v.z; }
+      else const_cast<float4*>(img)[at] = make_float4(d[0], d[1], d[2], alpha);
+    } else if (to_dense) {
+      d[0] = 0; d[1] = 0; d[2] = 0;
+    }
+  }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------
@@ -2321,6 +2347,19 @@ static inline size_t stack_lds_bytes(const FrameParams& P) {
   return (size_t)(P.tlas_stack + P.blas_stack) * 64 * (size_t)(P.block_threads / 64) * sizeof(int);
 }
 
+// What the last trace launch of this process was (urt_debug_launch_info): the instantiation's name as rocprofv3 prints it, its grid
+// and its dynamic LDS.  Written by the launchers below on the caller's (single) host thread; context.cpp copies it per context.
+static TraceLaunchRecord g_last_trace;
+const TraceLaunchRecord& last_trace_launch() { return g_last_trace; }
+static void note_launch(int n_blocks, int block_threads, size_t lds, const char* fmt, ...) __attribute__((format(printf, 4, 5)));
+static void note_launch(int n_blocks, int block_threads, size_t lds, const char* fmt, ...) {
+  va_list ap; va_start(ap, fmt);
+  vsnprintf(g_last_trace.kernel, sizeof g_last_trace.kernel, fmt, ap);
+  va_end(ap);
+  g_last_trace.n_blocks = n_blocks; g_last_trace.block_threads = block_threads; g_last_trace.lds_bytes = (int)lds;
+}
+static const char* tf(bool b) { return b ? "true" : "false"; }
+
 // dynamic LDS above the default 64 KiB per workgroup (very deep BVHs): the kernel's limit has to be raised first
 template <typename K>
 static hipError_t allow_lds(K kernel, size_t lds) {
@@ -2336,6 +2375,7 @@ hipError_t launch_mega(const DevScene& S, const FrameParams& P, float4* result, 
   if (ea != hipSuccess) return ea;
   if (count) hipLaunchKernelGGL(k_mega<true>, dim3(nb), dim3(P.block_threads), lds, st, S, P, result, ctr);
   else hipLaunchKernelGGL(k_mega<false>, dim3(nb), dim3(P.block_threads), lds, st, S, P, result, ctr);
+  note_launch(nb, P.block_threads, lds, "k_mega<%s>", tf(count));
   return hipGetLastError();
 }
 
@@ -2359,6 +2399,7 @@ hipError_t launch_wavefront(const DevScene& S, const FrameParams& P, const PathQ
       else hipLaunchKernelGGL(k_bounce<false>, dim3(nbb), dim3(bt), lds, st, S, P, Q, result, i, k, ctr);
     }
   }
+  note_launch(nbb, bt, lds, "k_generate + k_bounce<%s> x %d", tf(count), P.num_rays * P.num_bounces);
   return hipGetLastError();
 }
 
@@ -2372,6 +2413,7 @@ hipError_t launch_persist(const DevScene& S, const FrameParams& P, float4* resul
   if (e != hipSuccess) return e;
   if (count) hipLaunchKernelGGL(k_persist<true>, dim3(n_blocks), dim3(P.block_threads), lds, st, S, P, result, ctr, next);
   else hipLaunchKernelGGL(k_persist<false>, dim3(n_blocks), dim3(P.block_threads), lds, st, S, P, result, ctr, next);
+  note_launch(n_blocks, P.block_threads, lds, "k_persist<%s>", tf(count));
   return hipGetLastError();
 }
 
@@ -2393,6 +2435,7 @@ static hipError_t launch_sched_q(const DevScene& S, const FrameParams& P, const 
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL((k_sched<COUNT, BLOCK, FMODE, MULTI, QN>), dim3(n_blocks), dim3(BLOCK), lds, st, S, P, T, result, ctr, next);
+  note_launch(n_blocks, BLOCK, lds, "k_sched<%s, %d, %d, %s, %s>", tf(COUNT), BLOCK, FMODE, tf(MULTI), tf(QN));
   return hipGetLastError();
 }
 
@@ -2445,6 +2488,7 @@ static hipError_t launch_serve_t(const DevScene& S, const FrameParams& P, const 
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL((k_serve<COUNT, 256, FMODE, MULTI>), dim3(n_blocks), dim3(256), lds, st, S, P, T, result, ctr, next, mail);
+  note_launch(n_blocks, 256, lds, "k_serve<%s, 256, %d, %s>", tf(COUNT), FMODE, tf(MULTI));
   return hipGetLastError();
 }
 
@@ -2494,6 +2538,7 @@ static hipError_t launch_pool_k(const DevScene& S, const FrameParams& P, float4*
   }
   if (count) hipLaunchKernelGGL((k_pool<true, K>), dim3(n_blocks), dim3(64), lds, st, S, P, result, ctr, next);
   else hipLaunchKernelGGL((k_pool<false, K>), dim3(n_blocks), dim3(64), lds, st, S, P, result, ctr, next);
+  note_launch(n_blocks, 64, lds, "k_pool<%s, %d>", tf(count), K);
   return hipGetLastError();
 }
 
@@ -2539,6 +2584,17 @@ hipError_t launch_pack_rows(float4* img, float4* dense, int width, int height, i
   if (nb > 2048) nb = 2048;
   hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)nb), dim3(256), 0, st, (const float4*)img, dense, width, height,
                      first_group_row, row_stride, n_strips, to_dense ? 1 : 0);
+  return hipGetLastError();
+}
+
+hipError_t launch_pack_rows_rgb(float4* img, float* dense, int width, int height, int first_group_row, int row_stride,
+                                int n_strips, bool to_dense, float alpha, hipStream_t st) {
+  size_t n = (size_t)width * 8 * (size_t)n_strips;
+  if (n == 0) return hipSuccess;
+  size_t nb = (n + 255) / 256;
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(k_pack_rows_rgb, dim3((unsigned)nb), dim3(256), 0, st, (const float4*)img, dense, width, height,
+                     first_group_row, row_stride, n_strips, to_dense ? 1 : 0, alpha);
   return hipGetLastError();
 }
 

@@ -57,3 +57,15 @@ def gather_to_root(dist, mine, rank: int, world: int):
     parts = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
     dist.gather(mine, parts, dst=0)
     return parts
+
+
+def running_mean_alpha(samples) -> float:
+    """Alpha channel of `_converged` after AdditionShader blends with _Sample = s for s in `samples` (in order), starting from a fresh
+    (zero) image: the fragment's alpha is a = 1 / (s + 1) itself and is blended like the colours (AS:39-41), so every pixel holds
+    w <- a * a + w * (1 - a) in float32 — exactly the operations of k_blit_add.  What the root passes to urt_texture_unpack_rows_rgb."""
+    w = np.float32(0.0)
+    one = np.float32(1.0)
+    for s in samples:
+        a = one / (np.float32(s) + one)
+        w = np.float32(np.float32(a * a) + np.float32(w * np.float32(one - a)))
+    return float(w)

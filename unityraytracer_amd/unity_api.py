@@ -93,6 +93,12 @@ class Context:
         self.check(self.lib.urt_debug_scene_info(self._h, C.byref(nn), C.byref(nt), C.byref(md), C.byref(ms)))
         return {"n_nodes": nn.value, "n_tris": nt.value, "max_depth": md.value, "prepare_ms": ms.value}
 
+    def launch_info(self) -> dict:
+        """The last trace launch (deferred frames are submitted first): kernel instantiation by rocprofv3's name, grid, LDS, batching."""
+        li = _lib.LaunchInfo()
+        self.check(self.lib.urt_debug_launch_info(self._h, C.byref(li)))
+        return li.as_dict()
+
     def read_scene_blas(self, n_meshes: int):
         """(nodes[n,16], tri_index[n_tris], mesh_root[n_meshes]) of the current device scene, read back from the GPU."""
         info = self.scene_info()
@@ -234,8 +240,15 @@ class RenderTexture:
         self.ctx.check(self.ctx.lib.urt_texture_pack_rows(self.ctx._h, self.handle, first_group_row, row_stride, None, C.byref(n)))
         return n.value
 
-    def pack_rows(self, first_group_row: int, row_stride: int, device_dst: int):
-        self.ctx.check(self.ctx.lib.urt_texture_pack_rows(self.ctx._h, self.handle, first_group_row, row_stride, C.c_void_p(device_dst), None))
+    def pack_rows(self, first_group_row: int, row_stride: int, device_dst: int, rgb: bool = False):
+        """This rank's strips -> a dense device buffer; rgb: three channels per pixel (include/urt.h urt_texture_pack_rows_rgb)."""
+        fn = self.ctx.lib.urt_texture_pack_rows_rgb if rgb else self.ctx.lib.urt_texture_pack_rows
+        self.ctx.check(fn(self.ctx._h, self.handle, first_group_row, row_stride, C.c_void_p(device_dst), None))
+
+    def unpack_rows_rgb(self, first_group_row: int, row_stride: int, device_src: int, alpha: float, stream: int | None = None):
+        """De-interleave RGB strips into this image, writing `alpha` (running_mean_alpha) into the fourth channel."""
+        self.ctx.check(self.ctx.lib.urt_texture_unpack_rows_rgb(self.ctx._h, self.handle, first_group_row, row_stride, C.c_void_p(device_src),
+                                                                float(alpha), C.c_void_p(stream or 0)))
 
     def unpack_rows(self, first_group_row: int, row_stride: int, device_src: int, stream: int | None = None):
         """De-interleave packed strips into this image; `stream` = a caller-ordered hipStream_t (include/urt.h
