@@ -214,9 +214,9 @@ def test_two_hosts_interleaved_on_one_context(gpu_ctx):
 
 def test_rgb_strip_pack_and_unpack(gpu_ctx):
     """urt_texture_pack_rows_rgb / urt_texture_unpack_rows_rgb: three channels per pixel travel, the de-interleave writes the alpha it is
-    given; ragged last strip; the packed size is 12 B per pixel of the rank's padded strips."""
+    given; ragged last strip; the packed size is 12 B per pixel of the rank's padded strips.  (The dense buffer is the device memory of a
+    third image: no torch in this process — its bundled HIP runtime does not share a process with a library that initialised the GPU first.)"""
     import ctypes as C
-    import torch
     from unityraytracer_amd import RenderTexture, strips
     w, h, world = 40, 52, 3                                   # 7 group rows, the last with 4 pixel rows
     rng = np.random.default_rng(3)
@@ -225,22 +225,22 @@ def test_rgb_strip_pack_and_unpack(gpu_ctx):
     src.SetPixels(img)
     dst = RenderTexture(gpu_ctx, w, h)
     dst.SetPixels(np.zeros_like(img))
+    n_floats = strips.packed_rows(h, world) * w * 3
+    dense = RenderTexture(gpu_ctx, (n_floats + 3) // 4, 1)
     for rank in range(world):
         nb = C.c_uint64()
         gpu_ctx.check(gpu_ctx.lib.urt_texture_pack_rows_rgb(gpu_ctx._h, src.handle, rank, world, None, C.byref(nb)))
         assert nb.value == strips.n_strips(h, rank, world) * 8 * w * 12
-        buf = torch.full((strips.packed_rows(h, world) * w * 3,), -1.0, dtype=torch.float32, device="cuda")
-        torch.cuda.synchronize()
-        src.pack_rows(rank, world, buf.data_ptr(), rgb=True)
-        dst.unpack_rows_rgb(rank, world, buf.data_ptr(), 0.25)
-        gpu_ctx.synchronize()
-        host = buf.cpu().numpy().reshape(-1, w, 3)
+        dense.SetPixels(np.full((1, dense.width, 4), -1.0, np.float32))
+        src.pack_rows(rank, world, dense.device_ptr(), rgb=True)
+        dst.unpack_rows_rgb(rank, world, dense.device_ptr(), 0.25)
+        host = dense.GetPixels().reshape(-1)[:n_floats].reshape(-1, w, 3)
         for j, (y0, y1) in enumerate(strips.strip_row_ranges(h, rank, world)):
             assert np.array_equal(host[8 * j: 8 * j + (y1 - y0)], img[y0:y1, :, :3])
             assert (host[8 * j + (y1 - y0): 8 * j + 8] == 0).all()          # rows beyond the image are zero-filled
     got = dst.GetPixels()
     assert np.array_equal(got[..., :3], img[..., :3]) and (got[..., 3] == 0.25).all()
-    src.Release(); dst.Release()
+    src.Release(); dst.Release(); dense.Release()
 
 
 def test_launch_info_names_the_kernel_that_ran(gpu_ctx):
