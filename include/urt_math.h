@@ -295,6 +295,26 @@ URT_HD void cslab(float cx, float cy, float cz, float hx, float hy, float hz, co
 }
 
 // ---------------------------------------------------------------------------------------------
+// Object-level culling (not a reference function).  The reference intersects EVERY MeshObject whose heap leaf is popped once a first
+// leaf box was hit (`tests` is never reset, RS:296-326, A.5) — including objects whose box the ray misses, that lie behind its origin
+// or beyond the ground-plane hit (the slab test RS:271-291 has no t-range check).  A triangle of such an object cannot be the closest
+// hit, so the product skips the object when the reference's OWN slab values say so BY A MARGIN: t_min / t_max are the values RS:287-288
+// computes for the leaf's box, t_ground the hit distance after IntersectGroundPlane (+inf: none).  kappa = 1/64 of the t-values'
+// magnitude covers the rounding of the slab test and of Moller-Trumbore and the 2^-20 relative slack with which the library verifies
+// that the leaf's box really contains the object's triangles (csrc/cullflags.hip: only such leaves are ever culled); NaN / inf compare
+// false (no cull).  Counted, not assumed: tests compare the culled oracle with the literal brute force (tests/test_oracle_variants.py).
+// Shared by the kernels and the oracle's BVH-culled mode, so traversal counters stay equal event for event.
+// ---------------------------------------------------------------------------------------------
+URT_HD bool tlas_cull(float t_min, float t_max, float t_ground) {
+  const float kappa = 0.015625f;
+  float s = kappa * (f_abs(t_min) + f_abs(t_max));
+  bool miss = (t_min - t_max) > s;                                       // the ray's line passes the box
+  bool behind = t_max < -s;                                              // the box lies behind the origin
+  bool beyond = (t_min - t_ground) > kappa * (f_abs(t_min) + f_abs(t_ground));   // the box starts beyond the ground-plane hit
+  return miss || behind || beyond;
+}
+
+// ---------------------------------------------------------------------------------------------
 // rand()  (RS:77-81, A.1).  State: pixel (float2 of absolute pixel coordinates) + running seed.
 // ---------------------------------------------------------------------------------------------
 // x / c for a CONSTANT c whose correctly rounded reciprocal is y, without the divider: q = RN(x y), r = x - q c (exact, one

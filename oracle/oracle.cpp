@@ -58,6 +58,9 @@ struct OracleScene {
   const float* blas_nodes;            int32_t n_blas_nodes;     // 16 floats per node
   const int32_t* blas_tri_index;      int32_t n_blas_tris;      // leaf order -> index slot i (RS:243)
   const int32_t* blas_mesh_root;                                // per MeshObject
+  // mode 1 only: per MeshObject, 1 = the product's object-level cull applies to it (include/urt_math.h tlas_cull; filled by
+  // oracle_compute_cull_ok with the product's rule, csrc/cullflags.hip), or NULL = every popped object is intersected (the reference)
+  const int32_t* mesh_cull_ok;
 };
 
 struct OracleCounters {
@@ -282,10 +285,13 @@ struct Tracer {
   // DESIGN.md "normative arithmetic" (D3D `div` is itself specified to 1 ulp).
   // g_literal_division (a test-only switch, oracle_set_literal_division): evaluate RS:282-283 with the two divisions
   // written there instead — tests/test_oracle_variants.py counts the pixels that choice moves.
-  static bool IntersectBVHNode(const Ray& ray, const urt_BVHNode& node) {
+  static bool IntersectBVHNode(const Ray& ray, const urt_BVHNode& node) { float a, b; return IntersectBVHNode(ray, node, a, b); }
+  // (t_min / t_max as compared at RS:290 are handed out for the product's object-level cull; 0, 0 for an empty node)
+  static bool IntersectBVHNode(const Ray& ray, const urt_BVHNode& node, float& t_min, float& t_max) {
+    t_min = 0.0f; t_max = 0.0f;
     if (node.vmin[0] == node.vmax[0] && node.vmin[1] == node.vmax[1] && node.vmin[2] == node.vmax[2]) return false;
-    float t_min = -kFLOAT_MAX;
-    float t_max = kFLOAT_MAX;
+    t_min = -kFLOAT_MAX;
+    t_max = kFLOAT_MAX;
     const float o[3] = {ray.origin.x, ray.origin.y, ray.origin.z};
     const float d[3] = {ray.direction.x, ray.direction.y, ray.direction.z};
     for (int i = 0; i < 3; i++) {
@@ -313,6 +319,7 @@ struct Tracer {
     nodes[0] = 0;
     int check = 1;
     int tests = 0;
+    const float t_ground = bestHit.distance;                   // Trace() calls this right after IntersectGroundPlane (RS:369-376)
     while (check > 0) {
       check--;
       int BVHIndex = nodes[check];
@@ -320,7 +327,15 @@ struct Tracer {
       if (BVHIndex >= 0 && BVHIndex < S.n_mesh_bvh) node = S.mesh_bvh[BVHIndex];
       else std::memset(&node, 0, sizeof node);                 // out-of-range read = zeros
       C.tlas_nodes++;
-      if (IntersectBVHNode(ray, node)) {
+      float t_min, t_max;
+      bool passed = IntersectBVHNode(ray, node, t_min, t_max);
+      // BVH-culled mode only: the product's object-level cull (urt_math.h tlas_cull) — an object whose verified leaf box the ray passes,
+      // or that lies behind the origin or beyond the ground-plane hit, by a margin, cannot hold the closest hit and is skipped.  The
+      // literal mode 0 intersects it as the reference does; tests compare the two.
+      bool culled = mode == 1 && S.mesh_cull_ok && node.index >= 0 && node.index < S.n_mesh_objects && S.mesh_cull_ok[node.index] &&
+                    tlas_cull(t_min, t_max, t_ground);
+      if (culled) { if (passed && node.index >= 0) tests++; continue; }
+      if (passed) {
         if (node.index < 0) {
           nodes[check++] = BVHIndex * 2 + 1;
           nodes[check++] = BVHIndex * 2 + 2;
@@ -510,6 +525,38 @@ int oracle_render(const OracleScene* scene, int x0, int y0, int x1, int y1, int 
     for (auto& c : cs) add_counters(*counters, c);
   }
   return 0;
+}
+
+// The product's eligibility + verification rule for the object-level cull (csrc/context.cpp cull_words, csrc/cullflags.hip), restated:
+// MeshObject m may be culled iff the scene has >= 2 MeshObjects, exactly one node of the mesh heap names m, that node's box is not
+// empty (RS:273), m has at least one triangle, and every vertex of m's triangle records (v0, v0 + e1, v0 + e2 with e = v - v0 in
+// float32, as the product stores them) lies inside that box widened by 2^-20 of its largest |coordinate|.  out: n_mesh_objects ints.
+void oracle_compute_cull_ok(const OracleScene* S, int32_t* out) {
+  const int nm = S->n_mesh_objects;
+  for (int m = 0; m < nm; m++) out[m] = 0;
+  if (nm < 2 || S->n_mesh_bvh < 1) return;
+  std::vector<int> refs((size_t)nm, 0), leaf((size_t)nm, -1);
+  for (int i = 0; i < S->n_mesh_bvh; i++) { int ix = S->mesh_bvh[i].index; if (ix >= 0 && ix < nm) { refs[(size_t)ix]++; leaf[(size_t)ix] = i; } }
+  for (int m = 0; m < nm; m++) {
+    if (refs[(size_t)m] != 1) continue;
+    const urt_BVHNode& nd = S->mesh_bvh[leaf[(size_t)m]];
+    if (nd.vmin[0] == nd.vmax[0] && nd.vmin[1] == nd.vmax[1] && nd.vmin[2] == nd.vmax[2]) continue;
+    const urt_MeshObject& mo = S->mesh_objects[m];
+    if (mo.indices_count < 3) continue;
+    float M = 0.0f;
+    for (int a = 0; a < 3; a++) M = f_max(M, f_max(f_abs(nd.vmin[a]), f_abs(nd.vmax[a])));
+    const float tol = M * 9.5367431640625e-7f;
+    bool inside = true;
+    for (long i = mo.indices_offset; i + 2 < (long)mo.indices_offset + mo.indices_count && inside; i += 3) {
+      v3 p[3];
+      for (int k = 0; k < 3; k++) { const float* v = S->vertices + 3 * (size_t)S->indices[i + k]; p[k] = mul_m4(mo.localToWorldMatrix, v[0], v[1], v[2], 1.0f); }
+      v3 q[3] = {p[0], p[0] + (p[1] - p[0]), p[0] + (p[2] - p[0])};
+      for (int k = 0; k < 3; k++)
+        inside = inside && q[k].x >= nd.vmin[0] - tol && q[k].x <= nd.vmax[0] + tol && q[k].y >= nd.vmin[1] - tol && q[k].y <= nd.vmax[1] + tol &&
+                 q[k].z >= nd.vmin[2] - tol && q[k].z <= nd.vmax[2] + tol;
+    }
+    out[m] = inside ? 1 : 0;
+  }
 }
 
 // AS:9,39-41 driven as RM:817-818: frag returns (T.rgb, a), a = 1/(_Sample+1); blend

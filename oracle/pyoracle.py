@@ -33,6 +33,7 @@ class OracleScene(C.Structure):
         ("blas_nodes", C.c_void_p), ("n_blas_nodes", C.c_int32),
         ("blas_tri_index", C.c_void_p), ("n_blas_tris", C.c_int32),
         ("blas_mesh_root", C.c_void_p),
+        ("mesh_cull_ok", C.c_void_p),
     ]
 
 
@@ -57,6 +58,8 @@ def load(build: bool = True):
     vp, i = C.c_void_p, C.c_int
     lib.oracle_render.argtypes = [C.POINTER(OracleScene), i, i, i, i, i, i, vp, C.POINTER(OracleCounters)]
     lib.oracle_render.restype = i
+    lib.oracle_compute_cull_ok.argtypes = [C.POINTER(OracleScene), vp]
+    lib.oracle_compute_cull_ok.restype = None
     lib.oracle_accumulate.argtypes = [vp, vp, i, C.c_float]
     lib.oracle_accumulate.restype = None
     lib.oracle_math_probe.argtypes = [i, vp, vp, vp, vp, i]
@@ -124,8 +127,25 @@ class Oracle:
         s.num_bounces, s.num_rays = int(scene.num_bounces), int(scene.num_rays)
         s.width, s.height = int(scene.width), int(scene.height)
         self.s = s
+        self.set_cull(True)
         if blas is not None:
             self.set_blas(*blas)
+
+    def set_cull(self, on: bool = True):
+        """The product's object-level cull in the BVH-culled mode 1 (include/urt_math.h tlas_cull; on by default, like the library's
+        option front_cull): the per-MeshObject flags come from the oracle's restatement of the product's eligibility + verification
+        rule.  Mode 0 (literal brute force) never culls."""
+        k = self._keep
+        if on and len(k["mo"]) >= 2:
+            k["cull"] = np.zeros(len(k["mo"]), dtype=np.int32)
+            self.lib.oracle_compute_cull_ok(C.byref(self.s), _ptr(k["cull"]))
+            self.s.mesh_cull_ok = _ptr(k["cull"])
+        else:
+            k.pop("cull", None)
+            self.s.mesh_cull_ok = None
+
+    def cull_flags(self):
+        return None if "cull" not in self._keep else self._keep["cull"].copy()
 
     def set_frame(self, pixel_offset, seed):
         self.s.pixel_offset[:] = [float(pixel_offset[0]), float(pixel_offset[1])]

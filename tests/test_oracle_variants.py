@@ -103,3 +103,69 @@ def test_oracle_refuses_bvh_mode_without_a_triangle_bvh():
     with pytest.raises(ValueError):
         o.render(mode=1)
     assert np.isfinite(o.render(mode=0)).all()
+
+
+def test_object_level_cull_moves_no_pixel_and_skips_work():
+    """The product skips a MeshObject whose verified heap-leaf box the ray passes, or that lies behind the origin or beyond the ground-plane
+    hit, by a margin (include/urt_math.h tlas_cull) — the reference intersects it (RS:294-326: every popped leaf once `tests` is set).
+    Counted, not assumed: the culled BVH mode == the unculled BVH mode == the LITERAL brute force (mode 0, which never culls) on 40 random
+    multi-mesh scenes (rotated, non-uniformly scaled objects, quads, several bounces) and on reduced C4 / C5 / the reference's Scene1;
+    and the cull does skip triangle tests."""
+    import json
+    import os
+    from tests.test_gpu_fuzz import random_scene
+    from unityraytracer_amd import debug_build_blas, scenes
+    cases = []
+    for seed in range(3000, 3080):
+        sc, _, _ = random_scene(seed)
+        if len(sc.mesh_objects) >= 2:
+            cases.append(sc)
+        if len(cases) == 40:
+            break
+    cases += [scenes.CONFIGS["C4"](160, 90, slices=24, stacks=19), scenes.CONFIGS["C5"](160, 90, level=2)]
+    fx = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scene_Scene1.json")
+    if os.path.exists(fx):
+        cases.append(scenes.from_unity_fixture(json.load(open(fx)), 96, 54))
+    saved = culled_scenes = 0
+    for sc in cases:
+        o = pyoracle.Oracle(sc)
+        o.build_own_blas()
+        if o.s.n_blas_nodes <= 0:                            # (only single-leaf MeshObjects: the oracle's BVH mode wants at least one interior node)
+            continue
+        flags = o.cull_flags()
+        assert flags is not None and len(flags) == len(sc.mesh_objects)
+        a, ca = o.render(mode=1, threads=8, counters=True)
+        o.set_cull(False)
+        b, cb = o.render(mode=1, threads=8, counters=True)
+        lit = o.render(mode=0, threads=8)
+        assert np.array_equal(a.view(np.uint32), lit.view(np.uint32)), f"{sc.name}: the cull changed pixels against the literal brute force"
+        assert np.array_equal(b.view(np.uint32), lit.view(np.uint32)), sc.name
+        assert ca["rays"] == cb["rays"] and ca["tlas_nodes"] == cb["tlas_nodes"] and ca["tri_tests"] <= cb["tri_tests"] and ca["blas_nodes"] <= cb["blas_nodes"]
+        saved += cb["tri_tests"] + cb["blas_nodes"] - ca["tri_tests"] - ca["blas_nodes"]
+        culled_scenes += int(flags.any())
+    assert culled_scenes >= 30 and saved > 0, (culled_scenes, saved)
+
+
+def test_object_level_cull_needs_a_box_that_contains_the_object():
+    """A heap leaf whose box does NOT contain its MeshObject's triangles (the scene's data may say anything: `_MeshBVH` is an input) is
+    never culled — the verification rule clears its flag (oracle restatement of csrc/cullflags.hip; the GPU pass is tested in
+    tests/test_gpu_parity.py) — and a MeshObject that two leaves name is not eligible either."""
+    from unityraytracer_amd import scenes
+    sc = scenes.CONFIGS["C4"](64, 36, slices=12, stacks=9)
+    o = pyoracle.Oracle(sc)
+    assert o.cull_flags().all()
+    bad = sc.mesh_bvh.copy()
+    leaves = [i for i in range(len(bad)) if bad[i]["index"] >= 0]
+    i0 = leaves[0]
+    bad[i0]["vmax"] = bad[i0]["vmin"] + (bad[i0]["vmax"] - bad[i0]["vmin"]) * 0.5      # shrunk: half of the object pokes out
+    sc2 = scenes.Scene(sc.name, sc.width, sc.height, sc.num_bounces, sc.num_rays, mesh_objects=sc.mesh_objects, vertices=sc.vertices, indices=sc.indices,
+                       normals=sc.normals, mesh_bvh=bad, spheres=sc.spheres, sphere_bvh=sc.sphere_bvh, sky=sc.sky)
+    sc2.camera_to_world, sc2.camera_inverse_projection = sc.camera_to_world, sc.camera_inverse_projection
+    f2 = pyoracle.Oracle(sc2).cull_flags()
+    assert f2[bad[i0]["index"]] == 0 and f2.sum() == len(f2) - 1
+    dup = sc.mesh_bvh.copy()
+    dup[leaves[1]]["index"] = dup[leaves[0]]["index"]                                   # two leaves name one MeshObject, none names the other
+    sc3 = scenes.Scene(sc.name, sc.width, sc.height, sc.num_bounces, sc.num_rays, mesh_objects=sc.mesh_objects, vertices=sc.vertices, indices=sc.indices,
+                       normals=sc.normals, mesh_bvh=dup, spheres=sc.spheres, sphere_bvh=sc.sphere_bvh, sky=sc.sky)
+    f3 = pyoracle.Oracle(sc3).cull_flags()
+    assert f3[dup[leaves[0]]["index"]] == 0 and f3[sc.mesh_bvh[leaves[1]]["index"]] == 0

@@ -26,6 +26,7 @@
 #include "lbvh.h"
 #include "refit.h"
 #include "qnodes.h"
+#include "cullflags.h"
 #include "urt_device.h"
 
 #include <chrono>
@@ -193,6 +194,9 @@ struct urt_context {
   int opt_watchdog_cap = 0;                 // test hook: scheduler trips per wave (0 = auto, scaled with the launch)
   int slab_frames_max = 0;                  // largest batch the Result slab could be allocated for (after out-of-memory retries)
   urt_launch_info last_launch{};            // the last trace launch of this context (urt_debug_launch_info)
+  int opt_front_cull = 1;                   // object-level cull (urt_math.h tlas_cull; csrc/cullflags.hip): 0 = every popped object is intersected, as the reference does
+  int32_t* d_mesh_leaf = nullptr;           // per MeshObject: its heap leaf, or < 0 (in scene_allocs)
+  size_t cap_mesh_leaf = 0;
   size_t slab_oom_stride = 0;               // image size (pixels) for which not even two slots could be allocated
 };
 
@@ -241,7 +245,7 @@ void free_scene(urt_context* ctx) {
   ctx->scene_allocs.clear();
   ctx->ds = DevScene{};
   ctx->refit = urt_context::RefitAux{};
-  ctx->qbuf = nullptr; ctx->cbuf = nullptr;
+  ctx->qbuf = nullptr; ctx->cbuf = nullptr; ctx->d_mesh_leaf = nullptr; ctx->cap_mesh_leaf = 0;
   ctx->cap_materials = ctx->cap_mesh_tlas = ctx->cap_sphere_tlas = ctx->cap_sphere_pr = 0;
   ctx->slab_oom_stride = 0;                                // device memory came back: the next batch may try the Result slots again
 }
@@ -370,7 +374,7 @@ bool build_walk_table(const Buffer* heap, int n_meshes, const std::vector<int32_
   return true;
 }
 
-void pack_tlas(const Buffer* b, std::vector<float>& out) {
+void pack_tlas(const Buffer* b, std::vector<float>& out, const std::vector<int32_t>* cull_words) {
   out.clear();
   if (!b) return;
   out.resize((size_t)b->count * 8);
@@ -380,7 +384,65 @@ void pack_tlas(const Buffer* b, std::vector<float>& out) {
     float* o = out.data() + (size_t)i * 8;
     o[0] = nd.vmin[0]; o[1] = nd.vmin[1]; o[2] = nd.vmin[2]; std::memcpy(&o[3], &nd.index, 4);
     o[4] = nd.vmax[0]; o[5] = nd.vmax[1]; o[6] = nd.vmax[2]; o[7] = 0;
+    if (cull_words && (size_t)i < cull_words->size()) std::memcpy(&o[7], &(*cull_words)[(size_t)i], 4);      // (0 = never culled)
   }
+}
+
+// right-first pre-order position of every slot of the complete tree that holds an n-node heap (the pop order of RS:294-326; build_walk_table)
+void heap_positions(int n, std::vector<int>& pos, std::vector<int>& depth, int* levels, int* slots) {
+  const int D = heap_levels(n), N = (1 << D) - 1;
+  pos.assign((size_t)N, -1); depth.assign((size_t)N, 0);
+  std::vector<int> stack{0};
+  int next = 0;
+  while (!stack.empty()) {
+    int i = stack.back(); stack.pop_back();
+    pos[(size_t)i] = next++;
+    if (2 * i + 2 < N) { depth[(size_t)(2 * i + 1)] = depth[(size_t)(2 * i + 2)] = depth[(size_t)i] + 1; stack.push_back(2 * i + 1); stack.push_back(2 * i + 2); }
+  }
+  *levels = D; *slots = N;
+}
+
+// Object-level cull (urt_math.h tlas_cull): the cull word of every heap node — non-zero for the leaves that are ELIGIBLE: a MeshObject
+// with triangles that exactly one leaf of the heap names, in a scene of several MeshObjects (with one there is nothing to skip: the lone
+// object's own BVH rejects the ray at its root).  The word is the leaf's position bit of the masked walk (heaps of <= 31 nodes) or 1.
+// csrc/cullflags.hip then clears the word of every leaf whose box does not contain its object's triangles.  mesh_leaf[m] = that leaf, or -1.
+void cull_words(const urt_context* ctx, const Buffer* heap, int n_meshes, const std::vector<int32_t>& mesh_root, std::vector<int32_t>& words,
+                std::vector<int32_t>& mesh_leaf) {
+  const int n = heap ? heap->count : 0;
+  words.assign((size_t)n, 0);
+  mesh_leaf.assign((size_t)std::max(0, n_meshes), -1);
+  if (!ctx->opt_front_cull || n_meshes < 2 || n < 1) return;
+  std::vector<int> refs((size_t)n_meshes, 0);
+  auto node = [&](int i) { urt_BVHNode nd; std::memcpy(&nd, heap->host.data() + (size_t)i * URT_STRIDE_BVHNODE, sizeof nd); return nd; };
+  for (int i = 0; i < n; i++) { urt_BVHNode nd = node(i); if (nd.index >= 0 && nd.index < n_meshes) refs[(size_t)nd.index]++; }
+  std::vector<int> pos, depth; int D = 0, N = 0;
+  if (n <= 31) heap_positions(n, pos, depth, &D, &N);
+  for (int i = 0; i < n; i++) {
+    urt_BVHNode nd = node(i);
+    if (nd.index < 0 || nd.index >= n_meshes || refs[(size_t)nd.index] != 1) continue;
+    if ((size_t)nd.index >= mesh_root.size() || mesh_root[(size_t)nd.index] == kEmptyMeshRoot) continue;
+    if (nd.vmin[0] == nd.vmax[0] && nd.vmin[1] == nd.vmax[1] && nd.vmin[2] == nd.vmax[2]) continue;       // RS:273: never passes the slab test, its t values are not computed
+    words[(size_t)i] = n <= 31 ? (int32_t)(1u << pos[(size_t)i]) : 1;
+    mesh_leaf[(size_t)nd.index] = i;
+  }
+}
+
+// Upload mesh_leaf and run the verification pass over the prepared scene's triangle records (after a build and after every refit).
+int verify_cull_flags(urt_context* ctx, const std::vector<int32_t>& words, const std::vector<int32_t>& mesh_leaf) {
+  DevScene& S = ctx->ds;
+  bool any = false;
+  for (int32_t w : words) any = any || w != 0;
+  if (!any || S.n_mesh_tlas <= 0 || !S.mesh_tlas) return URT_OK;
+  if (mesh_leaf.size() > ctx->cap_mesh_leaf || !ctx->d_mesh_leaf) {
+    void* p = nullptr;
+    URT_HIP(ctx, hipMalloc(&p, std::max<size_t>(16, mesh_leaf.size() * sizeof(int32_t))));
+    ctx->scene_allocs.push_back(p);
+    ctx->d_mesh_leaf = (int32_t*)p; ctx->cap_mesh_leaf = mesh_leaf.size();
+  }
+  URT_HIP(ctx, hipMemcpy(ctx->d_mesh_leaf, mesh_leaf.data(), mesh_leaf.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  int* mask = ctx->walk_f4 > 0 ? (int*)const_cast<float4*>(S.mesh_tlas + 2 * (size_t)S.n_mesh_tlas) + 6 : nullptr;      // header word [6] of the walk table behind the heap
+  URT_HIP(ctx, update_cull_flags(const_cast<float4*>(S.mesh_tlas), S.n_mesh_tlas, ctx->d_mesh_leaf, S.n_meshes, S.tri_verts, ctx->n_scene_tris, mask, ctx->stream));
+  return URT_OK;
 }
 
 int requantize(urt_context* ctx);
@@ -426,7 +488,9 @@ int update_array(urt_context* ctx, const std::vector<float>& v, const float4** d
 }
 
 bool build_walk_table(const Buffer* heap, int n_meshes, const std::vector<int32_t>& mesh_root, const std::vector<int32_t>& small_first, std::vector<float>& out);
-void pack_tlas(const Buffer* b, std::vector<float>& out);
+void pack_tlas(const Buffer* b, std::vector<float>& out, const std::vector<int32_t>* cull_words = nullptr);
+void cull_words(const urt_context* ctx, const Buffer* heap, int n_meshes, const std::vector<int32_t>& mesh_root, std::vector<int32_t>& words, std::vector<int32_t>& mesh_leaf);
+int verify_cull_flags(urt_context* ctx, const std::vector<int32_t>& words, const std::vector<int32_t>& mesh_leaf);
 
 // The dynamic-scene path (RM:215-230: a moved object makes the reference re-upload every buffer).  When the only contents that changed
 // since the scene was prepared are those of _MeshObjects / _MeshBVH / _Spheres / _SphereBVH — same counts, same index ranges per
@@ -479,9 +543,11 @@ int prepare_incremental(urt_context* ctx) {
     if (n_spheres > 0 && (rc = update_array(ctx, pr, &S.sphere_pr, &ctx->cap_sphere_pr))) return rc;
   }
   // object-level heaps (+ the masked-walk table of a small mesh heap)
+  std::vector<int32_t> cw, mesh_leaf;
   {
     std::vector<float> t, walk;
-    pack_tlas(bmt, t);
+    cull_words(ctx, bmt, n_meshes, ctx->h_mesh_root, cw, mesh_leaf);
+    pack_tlas(bmt, t, &cw);
     ctx->walk_f4 = 0;
     if (n_meshes > 0 && build_walk_table(bmt, n_meshes, ctx->h_mesh_root, ctx->h_small_first, walk)) {
       ctx->walk_f4 = (int)(walk.size() / 4);
@@ -506,6 +572,7 @@ int prepare_incremental(urt_context* ctx) {
     ctx->refitted_meshes += (uint64_t)n_moved;
     if ((rc = rederive_nodes(ctx))) return rc;
   }
+  if ((rc = verify_cull_flags(ctx, cw, mesh_leaf))) return rc;       // against the (refitted) triangle records
   ctx->prev_mesh_objects.assign(bm ? bm->host.begin() : ctx->prev_mesh_objects.begin(), bm ? bm->host.begin() + (ptrdiff_t)((size_t)n_meshes * URT_STRIDE_MESHOBJECT) : ctx->prev_mesh_objects.begin());
   ctx->scene_dirty = false; ctx->dirty_slots = 0; ctx->dirty_full = false;
   ctx->scene_epoch++;
@@ -637,7 +704,9 @@ int prepare_scene(urt_context* ctx) {
   // object-level BVHs
   std::vector<float> t;
   const float4* p;
-  pack_tlas(bmt, t);
+  std::vector<int32_t> cw, mesh_leaf;
+  cull_words(ctx, bmt, n_meshes, mesh_root_host, cw, mesh_leaf);
+  pack_tlas(bmt, t, &cw);
   ctx->walk_f4 = 0;
   {   // the masked-walk table of a small mesh heap rides behind the heap's device copy (kernels.hip front_masked)
     std::vector<float> walk;
@@ -660,6 +729,8 @@ int prepare_scene(urt_context* ctx) {
   ctx->blas_stack = std::max(2, blas_max_depth + 1) + 1;      // + the sentinel entry below the stack (kernels.hip blas_node_eval_ptr)
   ctx->n_blas_nodes = (int)std::min<size_t>(0x7fffffff, n_blas_nodes);
   ctx->n_scene_tris = (int)n_tris; ctx->scene_max_depth = blas_max_depth;
+  ctx->d_mesh_leaf = nullptr; ctx->cap_mesh_leaf = 0;         // (freed with the previous scene's allocations)
+  if ((rc = verify_cull_flags(ctx, cw, mesh_leaf))) return rc;
   // a ray with NaN components passes every slab test and walks the whole tree once: (nodes + leaves) trips per lane, and the
   // majority vote can make a lane wait a trip for every trip it runs; 8x that is a bound no correct traversal reaches
   ctx->watchdog_steps = (unsigned int)std::min<size_t>(0x7fffffffu, 8 * (n_blas_nodes + n_tris) + 4096);
@@ -1772,6 +1843,9 @@ int urt_set_option(urt_context* ctx, const char* name, int value) {
     if (value < -1 || value > 1) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "qnodes must be -1 (auto), 0 or 1");
     ctx->opt_qnodes = value;
     ctx->scene_dirty = true; ctx->dirty_full = true;
+  } else if (std::strcmp(name, "front_cull") == 0) {
+    if (value < 0 || value > 1) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "front_cull must be 0 or 1");
+    if (ctx->opt_front_cull != value) { int rc = flush_pending(ctx); if (rc) return rc; ctx->opt_front_cull = value; ctx->scene_dirty = true; ctx->dirty_full = true; }
   } else if (std::strcmp(name, "refit") == 0) {
     ctx->opt_refit = value ? 1 : 0;
     ctx->scene_dirty = true; ctx->dirty_full = true;

@@ -73,6 +73,26 @@ __device__ __forceinline__ bool tlas_slab(float4 a, float4 b, v3 o, v3 rcp) {
   return t_max >= t_min;
 }
 
+// the same, handing out the t_min / t_max it compared (0, 0 for an empty node): what the object-level cull looks at (urt_math.h tlas_cull)
+__device__ __forceinline__ bool tlas_slab_t(float4 a, float4 b, v3 o, v3 rcp, float& t_min, float& t_max) {
+  t_min = 0.0f; t_max = 0.0f;
+  if (a.x == b.x && a.y == b.y && a.z == b.z) return false;      // RS:273 empty node
+  t_min = -kFLOAT_MAX; t_max = kFLOAT_MAX;
+  float t1 = (a.x - o.x) * rcp.x, t2 = (b.x - o.x) * rcp.x;
+  t_min = f_max(t_min, f_min(t1, t2)); t_max = f_min(t_max, f_max(t1, t2));
+  t1 = (a.y - o.y) * rcp.y; t2 = (b.y - o.y) * rcp.y;
+  t_min = f_max(t_min, f_min(t1, t2)); t_max = f_min(t_max, f_max(t1, t2));
+  t1 = (a.z - o.z) * rcp.z; t2 = (b.z - o.z) * rcp.z;
+  t_min = f_max(t_min, f_min(t1, t2)); t_max = f_min(t_max, f_max(t1, t2));
+  return t_max >= t_min;
+}
+// Object-level cull: the leaf's cull word (second float4 of the packed node, .w) is non-zero only when the library has verified that the
+// leaf's box contains the object's triangles (csrc/cullflags.hip); then the object is skipped when the reference's own slab values say the
+// ray passes the box, or the box lies behind the origin or beyond the ground-plane hit, by a margin (urt_math.h tlas_cull)
+__device__ __forceinline__ bool leaf_culled(float4 b, float t_min, float t_max, float t_ground) {
+  return as_int(b.w) != 0 && tlas_cull(t_min, t_max, t_ground);
+}
+
 // RS:175-196 without the material copy (fetched at shading time)
 template <bool COUNT>
 __device__ __forceinline__ void intersect_sphere(const DevScene& S, int idx, v3 o, v3 d, HitRec& best, LocalCounters& lc,
@@ -328,22 +348,25 @@ __device__ __forceinline__ HitRec trace(const DevScene& S, v3 o, v3 d, int* tl, 
   // IntersectMeshBVH RS:294-326 (`tests` is never reset: once a leaf was reached, every later popped
   // node has its object intersected, A.5; object ids < 0 or out of range are skipped, not read)
   if (S.n_meshes > 0) {
+    const float t_ground = best.t;                              // what the object-level cull compares with (urt_math.h tlas_cull)
     int check = 1; tl[0] = 0; bool seen = false;
     while (check > 0) {
       check--;
       int bi = tl[check * 64];
-      bool hit = false; int index = -1;
+      bool hit = false, culled = false; int index = -1;
       if (bi < S.n_mesh_tlas) {
         if (COUNT) lc.tlas_nodes++;
         float4 a = S.mesh_tlas[2 * bi], b = S.mesh_tlas[2 * bi + 1];
         index = as_int(a.w);
-        hit = tlas_slab(a, b, o, rcp);
+        float t_min, t_max;
+        hit = tlas_slab_t(a, b, o, rcp, t_min, t_max);
+        culled = leaf_culled(b, t_min, t_max, t_ground);
       }
       if (hit) {
         if (index < 0) { tl[check * 64] = bi * 2 + 1; check++; tl[check * 64] = bi * 2 + 2; check++; }
         else seen = true;
       }
-      if (seen && index >= 0 && index < S.n_meshes) intersect_mesh<COUNT>(S, S.mesh_root[index], o, d, best, bl, lc);
+      if (seen && !culled && index >= 0 && index < S.n_meshes) intersect_mesh<COUNT>(S, S.mesh_root[index], o, d, best, bl, lc);
     }
   }
   // IntersectSphereBVH RS:329-361
@@ -852,22 +875,28 @@ __device__ __forceinline__ bool trace_front(const DevScene& S, bool fresh, v3 o,
     if (S.n_meshes > 0) { check = 1; tl[0] = 0; }
   }
   v3 rcp = mk3(1.0f / (d.x + kEPSILON), 1.0f / (d.y + kEPSILON), 1.0f / (d.z + kEPSILON));
+  // the object-level cull compares with the ground-plane hit distance (urt_math.h tlas_cull): the walk resumes after triangle-BVH visits that
+  // have changed best.t, so it is re-derived here (the same operations as RS:156-172 above; single-mesh scenes have no cull words: skipped)
+  float t_ground = URT_INF;
+  const bool may_cull = S.n_meshes > 1;
+  if (may_cull && check > 0) { float t = -o.y / d.y; if (t > 0) t_ground = t; }
   while (check > 0) {                                        // IntersectMeshBVH RS:294-326
     check--;
     int bi = tl[check * stride];
-    bool hit = false; int index = -1;
+    bool hit = false, culled = false; int index = -1;
     if (bi < S.n_mesh_tlas) {
       if (COUNT) lc.tlas_nodes++;
       float4 a, b;
       if (L.mesh_tlas) { a = L.mesh_tlas[2 * bi]; b = L.mesh_tlas[2 * bi + 1]; } else { a = S.mesh_tlas[2 * bi]; b = S.mesh_tlas[2 * bi + 1]; }
       index = as_int(a.w);
-      hit = tlas_slab(a, b, o, rcp);
+      if (may_cull) { float t_min, t_max; hit = tlas_slab_t(a, b, o, rcp, t_min, t_max); culled = leaf_culled(b, t_min, t_max, t_ground); }
+      else hit = tlas_slab(a, b, o, rcp);
     }
     if (hit) {
       if (index < 0) { tl[check * stride] = bi * 2 + 1; check++; tl[check * stride] = bi * 2 + 2; check++; }
       else seen = true;
     }
-    if (seen && index >= 0 && index < S.n_meshes) {
+    if (seen && !culled && index >= 0 && index < S.n_meshes) {
       int32_t root;
       if (L.mesh_root) root = L.mesh_root[index]; else root = S.mesh_root[index];
       if (root < 0 && root != kBlasDone) {               // a mesh of <= 8 triangles is one leaf: test it here, no phase switch
@@ -965,21 +994,24 @@ __device__ __forceinline__ int front_listed(const DevScene& S, const FrameParams
     unsigned int l0 = 0, l1 = 0;
     bool seen = false;
     if (S.n_meshes > 0) { check = 1; tl[0] = 0; }
+    const float t_ground = best.t;                           // what the object-level cull compares with (urt_math.h tlas_cull)
     while (check > 0) {                                      // IntersectMeshBVH RS:294-326, the walk alone
       check--;
       int bi = tl[check * 64];
-      bool hit = false; int index = -1;
+      bool hit = false, culled = false; int index = -1;
       if (bi < S.n_mesh_tlas) {
         if (COUNT) lc.tlas_nodes++;
         float4 a = L.mesh_tlas[2 * bi], b = L.mesh_tlas[2 * bi + 1];
         index = as_int(a.w);
-        hit = tlas_slab(a, b, o, rcp);
+        float t_min, t_max;
+        hit = tlas_slab_t(a, b, o, rcp, t_min, t_max);
+        culled = leaf_culled(b, t_min, t_max, t_ground);
       }
       if (hit) {
         if (index < 0) { tl[check * 64] = bi * 2 + 1; check++; tl[check * 64] = bi * 2 + 2; check++; }
         else seen = true;
       }
-      if (seen && index >= 0 && index < S.n_meshes && L.mesh_root[index] != kEmptyMeshRoot) {
+      if (seen && !culled && index >= 0 && index < S.n_meshes && L.mesh_root[index] != kEmptyMeshRoot) {
         if (count < 6) l0 |= (unsigned int)index << (5 * count); else l1 |= (unsigned int)index << (5 * (count - 6));
         count++;
       }
@@ -1085,7 +1117,9 @@ __device__ __forceinline__ int front_masked(const DevScene& S, const FrameParams
       if (t > 0 && t < best.t) { best.t = t; best.kid = 1; }
     }
     v3 rcp = mk3(1.0f / (d.x + kEPSILON), 1.0f / (d.y + kEPSILON), 1.0f / (d.z + kEPSILON));
-    unsigned int H = 0;
+    unsigned int H = 0, Cm = 0;                              // slab test passed; object culled (urt_math.h tlas_cull)
+    const float t_ground = best.t;
+    const unsigned int cull_ok = (unsigned int)__builtin_amdgcn_readfirstlane(W.hdr[6]);   // leaves whose box was verified to contain their object (csrc/cullflags.hip)
     const int n_eval = __builtin_amdgcn_readfirstlane(W.hdr[0]);
     if (walker) for (int e = 0; e < n_eval; e++) {           // the slab tests that can matter, bounds broadcast from LDS
       float4 a = W.eval[2 * e], b = W.eval[2 * e + 1];
@@ -1101,6 +1135,8 @@ __device__ __forceinline__ int front_masked(const DevScene& S, const FrameParams
       t1 = (a.z - o.z) * rcp.z; t2 = (b.z - o.z) * rcp.z;
       t_min = f_max(t_min, f_min(t1, t2)); t_max = f_min(t_max, f_max(t1, t2));
       H |= t_max >= t_min ? (unsigned int)as_int(b.w) : 0u;
+      if (cull_ok & (unsigned int)__builtin_amdgcn_readfirstlane(as_int(b.w)))      // (wave-uniform: the entry is broadcast from LDS)
+        Cm |= tlas_cull(t_min, t_max, t_ground) ? (unsigned int)as_int(b.w) : 0u;
     }
     const unsigned int imask = (unsigned int)W.hdr[2];
     const int levels = __builtin_amdgcn_readfirstlane(W.hdr[1]);
@@ -1113,7 +1149,7 @@ __device__ __forceinline__ int front_masked(const DevScene& S, const FrameParams
     unsigned int src = Pm & H & (unsigned int)W.hdr[4];      // popped and hit leaves: the first one sets `tests` (RS:315), for good
     unsigned int Tn = 0;
     if (src) Tn = Pm & (unsigned int)W.hdr[5] & ~((1u << __builtin_ctz(src)) - 1u);
-    if (walker) T = Tn;
+    if (walker) T = Tn & ~Cm;
   }
   URT_FS(if (walk_now && n_fresh > 0) { fs[0] += wall_clock64() - fs_t0; fs[3]++; fs[6] += (unsigned long long)n_fresh; })
   bool need = false;
