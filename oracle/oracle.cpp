@@ -528,13 +528,13 @@ int oracle_render(const OracleScene* scene, int x0, int y0, int x1, int y1, int 
 }
 
 // The product's eligibility + verification rule for the object-level cull (csrc/context.cpp cull_words, csrc/cullflags.hip), restated:
-// MeshObject m may be culled iff the scene has >= 2 MeshObjects, exactly one node of the mesh heap names m, that node's box is not
+// MeshObject m may be culled iff exactly one node of the mesh heap names m, that node's box is not
 // empty (RS:273), m has at least one triangle, and every vertex of m's triangle records (v0, v0 + e1, v0 + e2 with e = v - v0 in
 // float32, as the product stores them) lies inside that box widened by 2^-20 of its largest |coordinate|.  out: n_mesh_objects ints.
 void oracle_compute_cull_ok(const OracleScene* S, int32_t* out) {
   const int nm = S->n_mesh_objects;
   for (int m = 0; m < nm; m++) out[m] = 0;
-  if (nm < 2 || S->n_mesh_bvh < 1) return;
+  if (nm < 1 || S->n_mesh_bvh < 1) return;
   std::vector<int> refs((size_t)nm, 0), leaf((size_t)nm, -1);
   for (int i = 0; i < S->n_mesh_bvh; i++) { int ix = S->mesh_bvh[i].index; if (ix >= 0 && ix < nm) { refs[(size_t)ix]++; leaf[(size_t)ix] = i; } }
   for (int m = 0; m < nm; m++) {

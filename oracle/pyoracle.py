@@ -136,7 +136,7 @@ class Oracle:
         option front_cull): the per-MeshObject flags come from the oracle's restatement of the product's eligibility + verification
         rule.  Mode 0 (literal brute force) never culls."""
         k = self._keep
-        if on and len(k["mo"]) >= 2:
+        if on and len(k["mo"]) >= 1:
             k["cull"] = np.zeros(len(k["mo"]), dtype=np.int32)
             self.lib.oracle_compute_cull_ok(C.byref(self.s), _ptr(k["cull"]))
             self.s.mesh_cull_ok = _ptr(k["cull"])

@@ -162,7 +162,7 @@ struct urt_context {
   // per dispatch), the AdditionShader blits that follow the dispatches are deferred with them and run in order after the
   // launch.  Everything else that could observe the images flushes first, so the in-order semantics of RM:806-820
   // stay exactly observable.
-  int opt_blas_builder = 0;                 // 0 = binned SAH on host threads (best trees), 1 = LBVH built on the GPU (dynamic scenes)
+  int opt_blas_builder = 0;                 // 0 = binned SAH on host threads (best trees), 1 = LBVH built on the GPU (dynamic scenes), 2 = the same tree built top-down within a depth budget (csrc/lbvh.hip k_td_level)
   float last_prepare_ms = 0;                // host wall time of the last scene preparation (buffers -> device scene)
   int n_scene_tris = 0;                     // triangles of the prepared scene
   int walk_f4 = 0;                          // float4s of the masked-walk table behind the mesh heap's device copy (0 = none: heap > 31 nodes)
@@ -403,15 +403,16 @@ void heap_positions(int n, std::vector<int>& pos, std::vector<int>& depth, int* 
 }
 
 // Object-level cull (urt_math.h tlas_cull): the cull word of every heap node — non-zero for the leaves that are ELIGIBLE: a MeshObject
-// with triangles that exactly one leaf of the heap names, in a scene of several MeshObjects (with one there is nothing to skip: the lone
-// object's own BVH rejects the ray at its root).  The word is the leaf's position bit of the masked walk (heaps of <= 31 nodes) or 1.
+// with triangles that exactly one leaf of the heap names.  (A lone MeshObject gains too: a ray that leaves it behind, or meets the ground
+// first, skips the round trip through the triangle-BVH phase — C3 -1.5 %, C3D -2.5 %, profiles/r04_logs/r4_ab_front_cull.log.)
+// The word is the leaf's position bit of the masked walk (heaps of <= 31 nodes) or 1.
 // csrc/cullflags.hip then clears the word of every leaf whose box does not contain its object's triangles.  mesh_leaf[m] = that leaf, or -1.
 void cull_words(const urt_context* ctx, const Buffer* heap, int n_meshes, const std::vector<int32_t>& mesh_root, std::vector<int32_t>& words,
                 std::vector<int32_t>& mesh_leaf) {
   const int n = heap ? heap->count : 0;
   words.assign((size_t)n, 0);
   mesh_leaf.assign((size_t)std::max(0, n_meshes), -1);
-  if (!ctx->opt_front_cull || n_meshes < 2 || n < 1) return;
+  if (!ctx->opt_front_cull || n_meshes < 1 || n < 1) return;
   std::vector<int> refs((size_t)n_meshes, 0);
   auto node = [&](int i) { urt_BVHNode nd; std::memcpy(&nd, heap->host.data() + (size_t)i * URT_STRIDE_BVHNODE, sizeof nd); return nd; };
   for (int i = 0; i < n; i++) { urt_BVHNode nd = node(i); if (nd.index >= 0 && nd.index < n_meshes) refs[(size_t)nd.index]++; }
@@ -432,7 +433,9 @@ int verify_cull_flags(urt_context* ctx, const std::vector<int32_t>& words, const
   DevScene& S = ctx->ds;
   bool any = false;
   for (int32_t w : words) any = any || w != 0;
+  S.cull_any = 0;
   if (!any || S.n_mesh_tlas <= 0 || !S.mesh_tlas) return URT_OK;
+  S.cull_any = 1;
   if (mesh_leaf.size() > ctx->cap_mesh_leaf || !ctx->d_mesh_leaf) {
     void* p = nullptr;
     URT_HIP(ctx, hipMalloc(&p, std::max<size_t>(16, mesh_leaf.size() * sizeof(int32_t))));
@@ -620,7 +623,7 @@ int prepare_scene(urt_context* ctx) {
       pack_material(mo.lighting, mats.data() + (size_t)(n_spheres + m) * kMatFloats);
     }
     const float4* p;
-    if (ctx->opt_blas_builder == 1) {
+    if (ctx->opt_blas_builder >= 1) {
       // device copies of the buffers exactly as SetData delivered them; the whole build runs on the GPU (csrc/lbvh.hip)
       std::vector<int32_t> offs((size_t)n_meshes), cnts((size_t)n_meshes);
       for (int m = 0; m < n_meshes; m++) {
@@ -644,7 +647,7 @@ int prepare_scene(urt_context* ctx) {
       in.vertices = bv ? (const float*)(rb + b_mo) : nullptr; in.n_vertices = bv ? bv->count : 0;
       in.indices = bi ? (const int32_t*)(rb + b_mo + b_v) : nullptr; in.n_indices = bi ? bi->count : 0;
       in.normals = bn ? (const float*)(rb + b_mo + b_v + b_i) : nullptr; in.n_normals = bn ? bn->count : 0;
-      in.h_offsets = offs.data(); in.h_counts = cnts.data(); in.leaf_max = get_blas_leaf_max();
+      in.h_offsets = offs.data(); in.h_counts = cnts.data(); in.leaf_max = get_blas_leaf_max(); in.depth_budget = ctx->opt_blas_builder >= 2; in.sah_splits = ctx->opt_blas_builder == 3;
       LbvhOutput o;
       std::string err;
       rc = lbvh_build(in, ctx->stream, o, err);
@@ -1753,7 +1756,7 @@ int urt_set_option(urt_context* ctx, const char* name, int value) {
   if (!name) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "option name is NULL");
   { (void)hipSetDevice(ctx->device); int rc = flush_pending(ctx); if (rc) return rc; }   // deferred frames run with the options they were dispatched under
   if (std::strcmp(name, "blas_builder") == 0) {
-    if (value < 0 || value > 1) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "blas_builder must be 0 (host SAH) or 1 (GPU LBVH)");
+    if (value < 0 || value > 3) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "blas_builder must be 0 (host SAH), 1 (GPU LBVH), 2 (GPU LBVH built top-down within a depth budget) or 3 (2 with surface-area split choice)");
     if (value != ctx->opt_blas_builder) { ctx->scene_dirty = true; ctx->dirty_full = true; }
     ctx->opt_blas_builder = value;
   } else if (std::strcmp(name, "frames_per_launch") == 0) {

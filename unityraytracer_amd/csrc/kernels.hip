@@ -876,9 +876,9 @@ __device__ __forceinline__ bool trace_front(const DevScene& S, bool fresh, v3 o,
   }
   v3 rcp = mk3(1.0f / (d.x + kEPSILON), 1.0f / (d.y + kEPSILON), 1.0f / (d.z + kEPSILON));
   // the object-level cull compares with the ground-plane hit distance (urt_math.h tlas_cull): the walk resumes after triangle-BVH visits that
-  // have changed best.t, so it is re-derived here (the same operations as RS:156-172 above; single-mesh scenes have no cull words: skipped)
+  // have changed best.t, so it is re-derived here (the same operations as RS:156-172 above; scenes without cull words skip all of it)
   float t_ground = URT_INF;
-  const bool may_cull = S.n_meshes > 1;
+  const bool may_cull = S.cull_any != 0;
   if (may_cull && check > 0) { float t = -o.y / d.y; if (t > 0) t_ground = t; }
   while (check > 0) {                                        // IntersectMeshBVH RS:294-326
     check--;

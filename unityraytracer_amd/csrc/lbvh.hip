@@ -61,7 +61,12 @@ struct Dev {
   int* is_top; int* top_id; int* flag; int* rank; int* queue;
   MeshStat* stats;                       // [kStatShards][n_meshes] then folded into shard 0
   int32_t* mesh_root;                    // out
-  int* scalars;                          // [0] error (index slot + 1), [1] max depth, [2] n_top
+  int* scalars;                          // [0] error (index slot + 1), [1] max depth, [2] n_top, [3] top-down builder: items queued for the next level
+  int* root_id;                          // [n_meshes] internal-node index of the MeshObject's root (Karras: the first position of its segment)
+  int4* tdq[2];                          // top-down builder (2): this level's and the next level's ranges {a, b, parent, side | depth << 1}
+  int depth_cap;                         // top-down builder: deepest level a leaf may sit on
+  // top-down builder with surface-area split choice (3): sparse table of boxes over the sorted triangles, level k at [k * T ..): box of [p, p + 2^k)
+  float4* st_lo; float4* st_hi; int st_levels;
   float4* nodes; float4* tri_verts; float4* tri_norms;      // out
 };
 
@@ -151,6 +156,7 @@ __global__ __launch_bounds__(64) void k_fold_stats(Dev D) {
     a.ext = max(a.ext, b.ext);
   }
   D.stats[m] = a;
+  D.root_id[m] = D.tri_first[m];                           // (the Karras tree's root; the top-down builder overwrites it)
   // MeshObjects without a tree of their own
   int n = D.tri_first[m + 1] - D.tri_first[m];
   if (n == 0) D.mesh_root[m] = kEmptyMeshRoot;
@@ -223,6 +229,107 @@ __global__ __launch_bounds__(256) void k_karras(Dev D) {
   D.parent[right >= 0 ? right : D.T + ~right] = i;
 }
 
+
+// ---- builder 2: the same radix tree built TOP-DOWN with a depth budget -------------------------------------------------------------
+// Karras' tree splits every range at its highest differing Morton bit, however lopsided: 30 levels on a 70 k-triangle mesh, against the
+// 21 of the host's SAH tree.  The traversal stacks live in LDS, one entry per level per lane, and their size decides how many workgroups
+// a CU holds: the depth ALONE costs +6 % (C3) ... +17 % (C4) frame time at equal tree quality (profiles/r04_logs/r4_ab_ploc_upper_tree.log,
+// stack_pad).  Here a range keeps its radix split only while the bigger side can still be finished by MEDIAN splits (in Morton order)
+// within the budget `depth_cap` = levels a median tree of the biggest MeshObject needs + 6; otherwise it is halved.  One launch per
+// level; a node's index is its split position (unique per internal node of a binary tree over the sorted positions), so the arrays the
+// rest of the pipeline reads — range, child, parent — come out in Karras' conventions.
+__device__ __forceinline__ int median_levels(int n, int leaf_max) {   // levels (interior + the leaf level) of a median-split tree over n triangles
+  int h = 1;
+  while (n > leaf_max) { n = (n + 1) >> 1; h++; }
+  return h;
+}
+
+__global__ __launch_bounds__(256) void k_st_level(Dev D, int k) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= D.T) return;
+  float4 lo, hi;
+  if (k == 0) { unsigned int g = D.vals_s[p]; lo = D.tlo[g]; hi = D.thi[g]; }
+  else {
+    const float4* L = D.st_lo + (size_t)(k - 1) * D.T; const float4* H = D.st_hi + (size_t)(k - 1) * D.T;
+    int q = min(p + (1 << (k - 1)), D.T - 1);
+    float4 a = L[p], b = H[p], c = L[q], d = H[q];
+    lo = make_float4(f_min(a.x, c.x), f_min(a.y, c.y), f_min(a.z, c.z), 0); hi = make_float4(f_max(b.x, d.x), f_max(b.y, d.y), f_max(b.z, d.z), 0);
+  }
+  D.st_lo[(size_t)k * D.T + p] = lo; D.st_hi[(size_t)k * D.T + p] = hi;
+}
+// half the surface area of the box of the sorted triangles [a, b] (inclusive), from the sparse table: two overlapping power-of-two blocks
+__device__ __forceinline__ float range_half_area(const Dev& D, int a, int b) {
+  int len = b - a + 1;
+  int k = 31 - __clz(len);
+  if (k >= D.st_levels) k = D.st_levels - 1;                  // (never: the table covers the biggest MeshObject)
+  const float4* L = D.st_lo + (size_t)k * D.T; const float4* H = D.st_hi + (size_t)k * D.T;
+  int q = b - (1 << k) + 1;
+  float4 l0 = L[a], h0 = H[a], l1 = L[q], h1 = H[q];
+  float dx = f_max(h0.x, h1.x) - f_min(l0.x, l1.x), dy = f_max(h0.y, h1.y) - f_min(l0.y, l1.y), dz = f_max(h0.z, h1.z) - f_min(l0.z, l1.z);
+  float A = dx * dy + dy * dz + dz * dx;
+  return A == A ? A : 3.0e38f;
+}
+
+__global__ __launch_bounds__(64) void k_td_roots(Dev D) {
+  int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= D.n_meshes) return;
+  int lo = D.tri_first[m], n = D.tri_first[m + 1] - lo;
+  if (n < 2) return;
+  int at = atomicAdd(D.scalars + 3, 1);
+  D.tdq[0][at] = make_int4(lo, lo + n - 1, -1 - m, 1 << 1);   // parent < 0: the root of MeshObject -1 - parent; depth 1
+}
+
+__global__ __launch_bounds__(256) void k_td_level(Dev D, int src, int n_items) {
+  int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n_items) return;
+  int4 it = D.tdq[src][q];
+  const int a = it.x, b = it.y, depth = it.w >> 1, side = it.w & 1;
+  const unsigned long long* K = D.keys_s;
+  // radix split: the last position whose key shares more than delta(a, b) leading bits with key a (Karras' search, from the left end)
+  int gamma;
+  {
+    const int dnode = delta(K, a, b, a, b);
+    int s = 0, t = b - a;
+    do {
+      t = (t + 1) >> 1;
+      if (a + s + t <= b && delta(K, a, a + s + t, a, b) > dnode) s += t;
+    } while (t > 1);
+    gamma = a + s;
+  }
+  const int size = b - a + 1;
+  int nl = gamma - a + 1, nr = size - nl;
+  if (D.st_levels > 0 && size > 4) {
+    // builder 3: of the radix split and seven evenly spaced positions, the one with the smallest surface-area cost A(L) n_L + A(R) n_R
+    // that keeps the subtree inside the depth budget (the middle position always does)
+    float best = URT_INF; int best_nl = (size + 1) >> 1;
+    for (int c = 0; c <= 7; c++) {
+      int cl = c == 0 ? nl : (int)(((long long)size * c) >> 3);
+      if (cl < 1 || cl >= size) continue;
+      if (median_levels(max(cl, size - cl), D.leaf_max) > D.depth_cap - depth) continue;
+      float cost = range_half_area(D, a, a + cl - 1) * (float)cl + range_half_area(D, a + cl, b) * (float)(size - cl);
+      if (cost < best) { best = cost; best_nl = cl; }
+    }
+    nl = best_nl; nr = size - nl; gamma = a + nl - 1;
+  } else
+  if (median_levels(max(nl, nr), D.leaf_max) > D.depth_cap - depth) { nl = (size + 1) >> 1; nr = size - nl; gamma = a + nl - 1; }   // over budget: halve (Morton order)
+  const int i = gamma;                                       // the node's index
+  D.range[i] = make_int2(a, b);
+  D.parent[i] = it.z >= 0 ? it.z : -1;
+  if (it.z >= 0) { if (side) D.child[it.z].y = i; else D.child[it.z].x = i; }
+  else D.root_id[-1 - it.z] = i;
+  int2 ch;
+  ch.x = nl == 1 ? ~a : 0; ch.y = nr == 1 ? ~b : 0;          // (interior children write themselves in at the next level)
+  D.child[i] = ch;
+  if (nl == 1) D.parent[D.T + a] = i;
+  if (nr == 1) D.parent[D.T + b] = i;
+  int n_new = (nl > 1) + (nr > 1);
+  if (n_new) {
+    int at = atomicAdd(D.scalars + 3, n_new);                // (queue order varies from run to run; the tree does not)
+    if (nl > 1) D.tdq[src ^ 1][at++] = make_int4(a, gamma, i, (0) | ((depth + 1) << 1));
+    if (nr > 1) D.tdq[src ^ 1][at] = make_int4(gamma + 1, b, i, (1) | ((depth + 1) << 1));
+  }
+}
+
 __device__ __forceinline__ void child_box(const Dev& D, int c, float4& lo, float4& hi) {
   if (c >= 0) { lo = D.nlo[c]; hi = D.nhi[c]; }
   else { unsigned int g = D.vals_s[~c]; lo = D.tlo[g]; hi = D.thi[g]; }
@@ -260,7 +367,7 @@ __global__ __launch_bounds__(256) void k_classify(Dev D) {
       int size = r.y - r.x + 1;
       keep = size > D.leaf_max;
       D.keep[i] = keep ? 1 : 0;
-      if (i == lo && !keep) { D.mesh_root[m] = leaf_code(lo, size); atomicMax(D.scalars + 1, 1); }   // the whole MeshObject is one leaf
+      if (i == D.root_id[m] && !keep) { D.mesh_root[m] = leaf_code(lo, size); atomicMax(D.scalars + 1, 1); }   // the whole MeshObject is one leaf
     }
   }
   int depth = 0;
@@ -279,7 +386,7 @@ __global__ __launch_bounds__(64) void k_top_bfs(Dev D) {
   int head = 0, tail = 0, next = 0;
   for (int m = 0; m < D.n_meshes; m++) {
     int lo = D.tri_first[m], n = D.tri_first[m + 1] - lo;
-    if (n >= 2 && D.keep[lo]) D.queue[tail++] = lo;
+    if (n >= 2 && D.keep[D.root_id[m]]) D.queue[tail++] = D.root_id[m];
   }
   while (head < tail && next < kTopOrderNodes) {
     int o = D.queue[head++];
@@ -321,7 +428,7 @@ __global__ __launch_bounds__(256) void k_emit_nodes(Dev D) {
   nd[1] = make_float4(hi[0].y + pad, hi[0].z + pad, lo[1].x - pad, lo[1].y - pad);
   nd[2] = make_float4(lo[1].z - pad, hi[1].x + pad, hi[1].y + pad, hi[1].z + pad);
   nd[3] = make_float4(__int_as_float(code[0]), __int_as_float(code[1]), 0.0f, 0.0f);
-  if (i == D.tri_first[m]) D.mesh_root[m] = id;
+  if (i == D.root_id[m]) D.mesh_root[m] = id;
 }
 
 __global__ __launch_bounds__(256) void k_emit_tris(Dev D) {
@@ -412,6 +519,15 @@ int lbvh_build(const LbvhInput& in, hipStream_t st, LbvhOutput& out, std::string
   const size_t o_queue = carve(4 * ((size_t)nm + 2 * (size_t)kTopOrderNodes + 8));
   const size_t o_stats = carve(sizeof(MeshStat) * (size_t)kStatShards * (size_t)nm);
   const size_t o_scalars = carve(64);
+  const size_t o_root_id = carve(4 * (size_t)nm);
+  int st_levels = 0;
+  if (in.depth_budget && in.sah_splits) {
+    int biggest = 1;
+    for (int m = 0; m < nm; m++) biggest = std::max(biggest, first[(size_t)m + 1] - first[(size_t)m]);
+    while ((1 << st_levels) <= biggest) st_levels++;          // levels 0 .. floor(log2(biggest))
+  }
+  const size_t o_st_lo = st_levels ? carve(sizeof(float4) * (size_t)T * (size_t)st_levels) : 0, o_st_hi = st_levels ? carve(sizeof(float4) * (size_t)T * (size_t)st_levels) : 0;
+  const size_t o_tdq0 = in.depth_budget ? carve(sizeof(int4) * (size_t)T) : 0, o_tdq1 = in.depth_budget ? carve(sizeof(int4) * (size_t)T) : 0;
   const size_t o_sort = carve(sort_bytes), o_scan = carve(scan_bytes);
   LBVH_HIP(hipMalloc(&temp, at));
   char* base = (char*)temp;
@@ -432,6 +548,16 @@ int lbvh_build(const LbvhInput& in, hipStream_t st, LbvhOutput& out, std::string
   D.stats = (MeshStat*)(base + o_stats);
   D.mesh_root = out.mesh_root;
   D.scalars = (int*)(base + o_scalars);
+  D.root_id = (int*)(base + o_root_id);
+  D.tdq[0] = (int4*)(base + o_tdq0); D.tdq[1] = (int4*)(base + o_tdq1);
+  D.st_lo = (float4*)(base + o_st_lo); D.st_hi = (float4*)(base + o_st_hi); D.st_levels = st_levels;
+  {   // depth budget of the top-down builder: what a median tree of the biggest MeshObject needs, + 6 levels of slack for lopsided radix splits
+    int biggest = 1;
+    for (int m = 0; m < nm; m++) biggest = std::max(biggest, first[(size_t)m + 1] - first[(size_t)m]);
+    int h = 1, n = biggest, lm = std::min(std::max(in.leaf_max, 1), 8);
+    while (n > lm) { n = (n + 1) >> 1; h++; }
+    D.depth_cap = h + 6;
+  }
   D.nodes = out.nodes; D.tri_verts = out.tri_verts; D.tri_norms = out.tri_norms;
 
   LBVH_HIP(hipMemcpyAsync(base + o_first, first.data(), sizeof(int32_t) * ((size_t)nm + 1), hipMemcpyHostToDevice, st));
@@ -444,7 +570,22 @@ int lbvh_build(const LbvhInput& in, hipStream_t st, LbvhOutput& out, std::string
   hipLaunchKernelGGL(k_fold_stats, dim3((unsigned int)((nm + 63) / 64)), dim3(64), 0, st, D);
   hipLaunchKernelGGL(k_morton, dim3(gb), dim3(256), 0, st, D);
   LBVH_HIP(rocprim::radix_sort_pairs(base + o_sort, sort_bytes, D.keys, D.keys_s, D.vals, D.vals_s, (size_t)T, 0, 32 + mesh_bits, st));
-  hipLaunchKernelGGL(k_karras, dim3(gb), dim3(256), 0, st, D);
+  if (!in.depth_budget) {
+    hipLaunchKernelGGL(k_karras, dim3(gb), dim3(256), 0, st, D);
+  } else {
+    for (int k = 0; k < st_levels; k++) hipLaunchKernelGGL(k_st_level, dim3(gb), dim3(256), 0, st, D, k);
+    hipLaunchKernelGGL(k_td_roots, dim3((unsigned int)((nm + 63) / 64)), dim3(64), 0, st, D);
+    int src = 0;
+    for (int level = 0; level < 64; level++) {
+      int n_items = 0;
+      LBVH_HIP(hipMemcpyAsync(&n_items, D.scalars + 3, sizeof(int), hipMemcpyDeviceToHost, st));
+      LBVH_HIP(hipStreamSynchronize(st));
+      if (n_items <= 0) break;
+      LBVH_HIP(hipMemsetAsync(D.scalars + 3, 0, sizeof(int), st));
+      hipLaunchKernelGGL(k_td_level, dim3((unsigned int)((n_items + 255) / 256)), dim3(256), 0, st, D, src, n_items);
+      src ^= 1;
+    }
+  }
   hipLaunchKernelGGL(k_fit, dim3(gb), dim3(256), 0, st, D);
   hipLaunchKernelGGL(k_classify, dim3(gb), dim3(256), 0, st, D);
   hipLaunchKernelGGL(k_top_bfs, dim3(1), dim3(64), 0, st, D);

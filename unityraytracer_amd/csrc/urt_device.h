@@ -40,6 +40,9 @@ struct DevScene {
   const float4* tri_norms;   // [3k..3k+2] n0, n1, n2 (object space, RS:259-261)
   // sky (RS:9-10): RGBA32F, row 0 = bottom, bilinear + repeat
   const float4* sky;         int sky_w, sky_h;
+  // object-level cull (urt_math.h tlas_cull): 1 = some leaf of the mesh heap carries a cull word (its box was verified to contain its
+  // MeshObject, csrc/cullflags.hip); 0 = the walk skips the cull arithmetic altogether
+  int cull_any;
 };
 
 struct FrameParams {
