@@ -178,7 +178,14 @@ typedef struct urt_counters {
 } urt_counters;
 /* Options: "blas_builder" (0 = binned-SAH triangle BVH built on host threads, the default: best trees; 1 = LBVH built on the GPU
  *                          from the uploaded buffers — Morton sort + Karras hierarchy, csrc/lbvh.hip: milliseconds instead of tens
- *                          of milliseconds for scenes whose objects move; same pixels),
+ *                          of milliseconds for scenes whose objects move; 2 = the same radix tree built top-down within a depth
+ *                          budget ("lbvh_slack", default 6 levels beyond a median tree): the traversal stacks live in LDS and a
+ *                          30-level Karras tree costs workgroups per CU — frames on tree 2 cost +6 ... +10 % against the SAH trees
+ *                          instead of +10 ... +26 %, the build 1 ms more on a million triangles; same pixels whichever builder),
+ *          "front_cull" (0/1, default 1: object-level cull — a MeshObject whose heap-leaf box the ray passes, leaves behind or meets
+ *                        beyond the ground-plane hit, by a margin, is not intersected although the reference would (RS:294-326 keeps
+ *                        testing every popped leaf once `tests` is set; such an object cannot hold the closest hit).  Only leaves whose
+ *                        box the library has verified to contain the object's triangles; 0 = the reference's literal work),
  *          "frames_per_launch" (0 = auto: own stream -> up to 64 frames per launch (fewer if their Result slots exceed 8 GiB), caller's stream -> 1;
  *                               1 = every dispatch is its own launch; 2..64 = batch that many, also on a caller's stream),
  *          "count_stats" (0/1: per-dispatch traversal counters, slower build of the kernel),

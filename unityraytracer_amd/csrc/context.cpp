@@ -194,6 +194,7 @@ struct urt_context {
   int opt_watchdog_cap = 0;                 // test hook: scheduler trips per wave (0 = auto, scaled with the launch)
   int slab_frames_max = 0;                  // largest batch the Result slab could be allocated for (after out-of-memory retries)
   urt_launch_info last_launch{};            // the last trace launch of this context (urt_debug_launch_info)
+  int opt_lbvh_slack = 6;                   // blas_builder 2: levels of slack in the depth budget (csrc/lbvh.hip k_td_level)
   int opt_front_cull = 1;                   // object-level cull (urt_math.h tlas_cull; csrc/cullflags.hip): 0 = every popped object is intersected, as the reference does
   int32_t* d_mesh_leaf = nullptr;           // per MeshObject: its heap leaf, or < 0 (in scene_allocs)
   size_t cap_mesh_leaf = 0;
@@ -647,7 +648,7 @@ int prepare_scene(urt_context* ctx) {
       in.vertices = bv ? (const float*)(rb + b_mo) : nullptr; in.n_vertices = bv ? bv->count : 0;
       in.indices = bi ? (const int32_t*)(rb + b_mo + b_v) : nullptr; in.n_indices = bi ? bi->count : 0;
       in.normals = bn ? (const float*)(rb + b_mo + b_v + b_i) : nullptr; in.n_normals = bn ? bn->count : 0;
-      in.h_offsets = offs.data(); in.h_counts = cnts.data(); in.leaf_max = get_blas_leaf_max(); in.depth_budget = ctx->opt_blas_builder >= 2; in.sah_splits = ctx->opt_blas_builder == 3;
+      in.h_offsets = offs.data(); in.h_counts = cnts.data(); in.leaf_max = get_blas_leaf_max(); in.depth_budget = ctx->opt_blas_builder == 2; in.depth_slack = ctx->opt_lbvh_slack;
       LbvhOutput o;
       std::string err;
       rc = lbvh_build(in, ctx->stream, o, err);
@@ -1756,7 +1757,7 @@ int urt_set_option(urt_context* ctx, const char* name, int value) {
   if (!name) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "option name is NULL");
   { (void)hipSetDevice(ctx->device); int rc = flush_pending(ctx); if (rc) return rc; }   // deferred frames run with the options they were dispatched under
   if (std::strcmp(name, "blas_builder") == 0) {
-    if (value < 0 || value > 3) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "blas_builder must be 0 (host SAH), 1 (GPU LBVH), 2 (GPU LBVH built top-down within a depth budget) or 3 (2 with surface-area split choice)");
+    if (value < 0 || value > 2) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "blas_builder must be 0 (host SAH), 1 (GPU LBVH) or 2 (GPU LBVH built top-down within a depth budget)");
     if (value != ctx->opt_blas_builder) { ctx->scene_dirty = true; ctx->dirty_full = true; }
     ctx->opt_blas_builder = value;
   } else if (std::strcmp(name, "frames_per_launch") == 0) {
@@ -1846,6 +1847,10 @@ int urt_set_option(urt_context* ctx, const char* name, int value) {
     if (value < -1 || value > 1) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "qnodes must be -1 (auto), 0 or 1");
     ctx->opt_qnodes = value;
     ctx->scene_dirty = true; ctx->dirty_full = true;
+  } else if (std::strcmp(name, "lbvh_slack") == 0) {
+    if (value < 0 || value > 16) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "lbvh_slack must be 0..16");
+    if (value != ctx->opt_lbvh_slack) { ctx->scene_dirty = true; ctx->dirty_full = true; }
+    ctx->opt_lbvh_slack = value;
   } else if (std::strcmp(name, "front_cull") == 0) {
     if (value < 0 || value > 1) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "front_cull must be 0 or 1");
     if (ctx->opt_front_cull != value) { int rc = flush_pending(ctx); if (rc) return rc; ctx->opt_front_cull = value; ctx->scene_dirty = true; ctx->dirty_full = true; }

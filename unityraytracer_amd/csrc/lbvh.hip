@@ -65,8 +65,6 @@ struct Dev {
   int* root_id;                          // [n_meshes] internal-node index of the MeshObject's root (Karras: the first position of its segment)
   int4* tdq[2];                          // top-down builder (2): this level's and the next level's ranges {a, b, parent, side | depth << 1}
   int depth_cap;                         // top-down builder: deepest level a leaf may sit on
-  // top-down builder with surface-area split choice (3): sparse table of boxes over the sorted triangles, level k at [k * T ..): box of [p, p + 2^k)
-  float4* st_lo; float4* st_hi; int st_levels;
   float4* nodes; float4* tri_verts; float4* tri_norms;      // out
 };
 
@@ -244,32 +242,6 @@ __device__ __forceinline__ int median_levels(int n, int leaf_max) {   // levels 
   return h;
 }
 
-__global__ __launch_bounds__(256) void k_st_level(Dev D, int k) {
-  int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= D.T) return;
-  float4 lo, hi;
-  if (k == 0) { unsigned int g = D.vals_s[p]; lo = D.tlo[g]; hi = D.thi[g]; }
-  else {
-    const float4* L = D.st_lo + (size_t)(k - 1) * D.T; const float4* H = D.st_hi + (size_t)(k - 1) * D.T;
-    int q = min(p + (1 << (k - 1)), D.T - 1);
-    float4 a = L[p], b = H[p], c = L[q], d = H[q];
-    lo = make_float4(f_min(a.x, c.x), f_min(a.y, c.y), f_min(a.z, c.z), 0); hi = make_float4(f_max(b.x, d.x), f_max(b.y, d.y), f_max(b.z, d.z), 0);
-  }
-  D.st_lo[(size_t)k * D.T + p] = lo; D.st_hi[(size_t)k * D.T + p] = hi;
-}
-// half the surface area of the box of the sorted triangles [a, b] (inclusive), from the sparse table: two overlapping power-of-two blocks
-__device__ __forceinline__ float range_half_area(const Dev& D, int a, int b) {
-  int len = b - a + 1;
-  int k = 31 - __clz(len);
-  if (k >= D.st_levels) k = D.st_levels - 1;                  // (never: the table covers the biggest MeshObject)
-  const float4* L = D.st_lo + (size_t)k * D.T; const float4* H = D.st_hi + (size_t)k * D.T;
-  int q = b - (1 << k) + 1;
-  float4 l0 = L[a], h0 = H[a], l1 = L[q], h1 = H[q];
-  float dx = f_max(h0.x, h1.x) - f_min(l0.x, l1.x), dy = f_max(h0.y, h1.y) - f_min(l0.y, l1.y), dz = f_max(h0.z, h1.z) - f_min(l0.z, l1.z);
-  float A = dx * dy + dy * dz + dz * dx;
-  return A == A ? A : 3.0e38f;
-}
-
 __global__ __launch_bounds__(64) void k_td_roots(Dev D) {
   int m = blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= D.n_meshes) return;
@@ -298,19 +270,6 @@ __global__ __launch_bounds__(256) void k_td_level(Dev D, int src, int n_items) {
   }
   const int size = b - a + 1;
   int nl = gamma - a + 1, nr = size - nl;
-  if (D.st_levels > 0 && size > 4) {
-    // builder 3: of the radix split and seven evenly spaced positions, the one with the smallest surface-area cost A(L) n_L + A(R) n_R
-    // that keeps the subtree inside the depth budget (the middle position always does)
-    float best = URT_INF; int best_nl = (size + 1) >> 1;
-    for (int c = 0; c <= 7; c++) {
-      int cl = c == 0 ? nl : (int)(((long long)size * c) >> 3);
-      if (cl < 1 || cl >= size) continue;
-      if (median_levels(max(cl, size - cl), D.leaf_max) > D.depth_cap - depth) continue;
-      float cost = range_half_area(D, a, a + cl - 1) * (float)cl + range_half_area(D, a + cl, b) * (float)(size - cl);
-      if (cost < best) { best = cost; best_nl = cl; }
-    }
-    nl = best_nl; nr = size - nl; gamma = a + nl - 1;
-  } else
   if (median_levels(max(nl, nr), D.leaf_max) > D.depth_cap - depth) { nl = (size + 1) >> 1; nr = size - nl; gamma = a + nl - 1; }   // over budget: halve (Morton order)
   const int i = gamma;                                       // the node's index
   D.range[i] = make_int2(a, b);
@@ -520,13 +479,6 @@ int lbvh_build(const LbvhInput& in, hipStream_t st, LbvhOutput& out, std::string
   const size_t o_stats = carve(sizeof(MeshStat) * (size_t)kStatShards * (size_t)nm);
   const size_t o_scalars = carve(64);
   const size_t o_root_id = carve(4 * (size_t)nm);
-  int st_levels = 0;
-  if (in.depth_budget && in.sah_splits) {
-    int biggest = 1;
-    for (int m = 0; m < nm; m++) biggest = std::max(biggest, first[(size_t)m + 1] - first[(size_t)m]);
-    while ((1 << st_levels) <= biggest) st_levels++;          // levels 0 .. floor(log2(biggest))
-  }
-  const size_t o_st_lo = st_levels ? carve(sizeof(float4) * (size_t)T * (size_t)st_levels) : 0, o_st_hi = st_levels ? carve(sizeof(float4) * (size_t)T * (size_t)st_levels) : 0;
   const size_t o_tdq0 = in.depth_budget ? carve(sizeof(int4) * (size_t)T) : 0, o_tdq1 = in.depth_budget ? carve(sizeof(int4) * (size_t)T) : 0;
   const size_t o_sort = carve(sort_bytes), o_scan = carve(scan_bytes);
   LBVH_HIP(hipMalloc(&temp, at));
@@ -550,13 +502,12 @@ int lbvh_build(const LbvhInput& in, hipStream_t st, LbvhOutput& out, std::string
   D.scalars = (int*)(base + o_scalars);
   D.root_id = (int*)(base + o_root_id);
   D.tdq[0] = (int4*)(base + o_tdq0); D.tdq[1] = (int4*)(base + o_tdq1);
-  D.st_lo = (float4*)(base + o_st_lo); D.st_hi = (float4*)(base + o_st_hi); D.st_levels = st_levels;
   {   // depth budget of the top-down builder: what a median tree of the biggest MeshObject needs, + 6 levels of slack for lopsided radix splits
     int biggest = 1;
     for (int m = 0; m < nm; m++) biggest = std::max(biggest, first[(size_t)m + 1] - first[(size_t)m]);
     int h = 1, n = biggest, lm = std::min(std::max(in.leaf_max, 1), 8);
     while (n > lm) { n = (n + 1) >> 1; h++; }
-    D.depth_cap = h + 6;
+    D.depth_cap = h + in.depth_slack;
   }
   D.nodes = out.nodes; D.tri_verts = out.tri_verts; D.tri_norms = out.tri_norms;
 
@@ -573,7 +524,6 @@ int lbvh_build(const LbvhInput& in, hipStream_t st, LbvhOutput& out, std::string
   if (!in.depth_budget) {
     hipLaunchKernelGGL(k_karras, dim3(gb), dim3(256), 0, st, D);
   } else {
-    for (int k = 0; k < st_levels; k++) hipLaunchKernelGGL(k_st_level, dim3(gb), dim3(256), 0, st, D, k);
     hipLaunchKernelGGL(k_td_roots, dim3((unsigned int)((nm + 63) / 64)), dim3(64), 0, st, D);
     int src = 0;
     for (int level = 0; level < 64; level++) {
