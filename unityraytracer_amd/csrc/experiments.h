@@ -10,7 +10,7 @@
 
 #if defined(URT_PROBE_NOSTORE) || defined(URT_EXTRA_NODE_LOADS) || defined(URT_MINORITY) || defined(URT_VOTE_NUM) || defined(URT_VOTE_DEN) || \
     defined(URT_LDS_LEAF_SINGLE) || defined(URT_STAMPS) || defined(URT_SCHED_OCC) || defined(URT_SERVE_OCC) || defined(URT_SERVE_SLEEP) || \
-    defined(URT_SKY_FASTWRAP) || defined(URT_SAH_BINS) || defined(URT_SPECULATE_LEAF) || defined(URT_AB)
+    defined(URT_SKY_FASTWRAP) || defined(URT_SAH_BINS) || defined(URT_AB)
 #ifndef URT_EXPERIMENT
 #error "A/B, probe and diagnostic switches (-DURT_STAMPS, -DURT_PROBE_*, -DURT_MINORITY, ...) need -DURT_EXPERIMENT: the library then reports a negative urt_abi_version and loaders refuse it unless they opt in (csrc/experiments.h)"
 #endif
