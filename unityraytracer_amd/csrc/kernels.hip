@@ -141,12 +141,6 @@ __device__ __forceinline__ void test_leaf(const DevScene& S, int32_t leaf, v3 o,
   uint32_t code = ~(uint32_t)leaf;
   uint32_t first = code >> 3, cnt = (code & 7u) + 1u;
   if (lds_first >= 0) {
-#ifdef URT_LDS_LEAF_SINGLE                   // A/B build: one record at a time (rounds 2-3)
-    for (uint32_t k = 0; k < cnt; k++) {
-      const float4* t = lds_tris + 3 * ((uint32_t)lds_first + k);
-      test_triangle<COUNT>(t[0], t[1], t[2], (int)(first + k), o, d, best, best_i, lc);
-    }
-#else
     for (uint32_t k = 0; k < cnt; k += 2) {            // two records per round, both read before either is tested (a wall quad is one round)
       const bool two = k + 1 < cnt;
       const float4* ta = lds_tris + 3 * ((uint32_t)lds_first + k);
@@ -156,7 +150,6 @@ __device__ __forceinline__ void test_leaf(const DevScene& S, int32_t leaf, v3 o,
       test_triangle<COUNT>(a0, a1, a2, (int)(first + k), o, d, best, best_i, lc);
       if (two) test_triangle<COUNT>(b0, b1, b2, (int)(first + k + 1), o, d, best, best_i, lc);
     }
-#endif
     return;
   }
   // two triangles per round: both records are requested before either is tested, so a leaf of 4 costs two memory
@@ -416,9 +409,6 @@ __device__ __forceinline__ v3 sample_hemisphere(v3 normal, float inv_alpha1, flo
 typedef float f4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void st_result(float4* p, float4 v) {
   f4v q = {v.x, v.y, v.z, v.w};
-#ifdef URT_PROBE_NOSTORE                     // timing probe only (wrong images): what do the Result stores cost the waves that issue them?
-  if (v.x != 1234567.0f) return;
-#endif
   __builtin_nontemporal_store(q, (f4v*)p);
 }
 
@@ -875,27 +865,29 @@ __device__ __forceinline__ bool trace_front(const DevScene& S, bool fresh, v3 o,
     if (S.n_meshes > 0) { check = 1; tl[0] = 0; }
   }
   v3 rcp = mk3(1.0f / (d.x + kEPSILON), 1.0f / (d.y + kEPSILON), 1.0f / (d.z + kEPSILON));
-  // the object-level cull compares with the ground-plane hit distance (urt_math.h tlas_cull): the walk resumes after triangle-BVH visits that
-  // have changed best.t, so it is re-derived here (the same operations as RS:156-172 above; scenes without cull words skip all of it)
-  float t_ground = URT_INF;
+  // the object-level cull (urt_math.h tlas_cull) compares with the ground-plane hit distance; the walk resumes after triangle-BVH visits that
+  // have changed best.t, so that distance is re-derived where a leaf with a cull word is met (the same operations as RS:156-172 above — and
+  // only there: kept live across the loop it cost 32 B/lane of scratch in the single-mesh instantiation)
   const bool may_cull = S.cull_any != 0;
-  if (may_cull && check > 0) { float t = -o.y / d.y; if (t > 0) t_ground = t; }
   while (check > 0) {                                        // IntersectMeshBVH RS:294-326
     check--;
     int bi = tl[check * stride];
-    bool hit = false, culled = false; int index = -1;
+    bool hit = false; int index = -1;
+    float t_min = 0.0f, t_max = 0.0f; int cull_word = 0;
     if (bi < S.n_mesh_tlas) {
       if (COUNT) lc.tlas_nodes++;
       float4 a, b;
       if (L.mesh_tlas) { a = L.mesh_tlas[2 * bi]; b = L.mesh_tlas[2 * bi + 1]; } else { a = S.mesh_tlas[2 * bi]; b = S.mesh_tlas[2 * bi + 1]; }
       index = as_int(a.w);
-      if (may_cull) { float t_min, t_max; hit = tlas_slab_t(a, b, o, rcp, t_min, t_max); culled = leaf_culled(b, t_min, t_max, t_ground); }
+      if (may_cull) { hit = tlas_slab_t(a, b, o, rcp, t_min, t_max); cull_word = as_int(b.w); }
       else hit = tlas_slab(a, b, o, rcp);
     }
     if (hit) {
       if (index < 0) { tl[check * stride] = bi * 2 + 1; check++; tl[check * stride] = bi * 2 + 2; check++; }
       else seen = true;
     }
+    bool culled = false;
+    if (cull_word != 0) { float t = -o.y / d.y; culled = tlas_cull(t_min, t_max, t > 0 ? t : URT_INF); }      // (the ground-plane hit distance, re-derived: RS:156-172)
     if (seen && !culled && index >= 0 && index < S.n_meshes) {
       int32_t root;
       if (L.mesh_root) root = L.mesh_root[index]; else root = S.mesh_root[index];
@@ -1446,9 +1438,6 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
       const int exit_s = __builtin_amdgcn_readfirstlane(exit_below);
       QRay Q;
       if (QN) Q = make_qray(o, d, S.blas_qnodes[0], S.blas_qnodes[1]);     // the grid frame: two wave-uniform loads per phase entry
-#ifdef URT_MINORITY
-      int starve = 0;
-#endif
       for (;;) {
         int nA = __popcll(wballot(c != kBlasDone));
         if (nA < exit_s) break;
@@ -1460,20 +1449,9 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
         // majority vote: this trip runs EITHER the interior-node step OR the leaf step, for the lanes that hold that kind
         // of cursor (the others wait one trip) — so a trip costs one of the two bodies, not their sum.
         int nI = __popcll(wballot(c >= 0));
-#ifndef URT_VOTE_NUM                       // A/B builds: node trip iff nI * URT_VOTE_DEN >= nA * URT_VOTE_NUM (default 1/2: the majority)
-#define URT_VOTE_NUM 1
-#define URT_VOTE_DEN 2
-#endif
-        bool node_trip = URT_VOTE_DEN * nI >= URT_VOTE_NUM * nA;
+        bool node_trip = 2 * nI >= nA;             // (weighting the vote 1/3 or 2/3: +0.4 % / +2 %; a minority step: +4 ... +7 % — profiles/r03_logs/r3_ab_vote_xload.log, r3_ab_minority.log)
 #ifdef URT_STAMPS
         bl_part[0] += (unsigned long long)(node_trip ? nI : nA - nI); bl_part[1] += node_trip ? 1 : 0; bl_part[2] += (unsigned long long)(node_trip ? nA - nI : 0);
-#endif
-#ifdef URT_MINORITY                          // A/B build: when the minority kind has held >= 40 % of the active lanes for two trips, it gets this trip
-        {
-          int nMin = min(nI, nA - nI);
-          starve = 5 * nMin >= 2 * nA ? starve + 1 : 0;
-          if (starve >= 2) { node_trip = !node_trip; starve = 0; }
-        }
 #endif
         if (node_trip) {
           if (QN) {
@@ -1486,9 +1464,6 @@ __global__ __launch_bounds__(BLOCK, URT_SCHED_OCC) void k_sched(DevScene S, Fram
             if (COUNT) lc.blas_nodes++;
             const float4* n = (const float4*)((const char*)S.blas_cnodes + ((uint32_t)c << 6));
             float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
-#ifdef URT_EXTRA_NODE_LOADS                // A/B probe: how sensitive is the loop to vector-memory instructions per node step?
-            { const float4* n2 = (const float4*)((const char*)S.blas_cnodes + ((uint32_t)(c > 0 ? c - 1 : c + 1) << 6)); float4 x0 = n2[0], x1 = n2[1]; asm volatile("" :: "v"(x0.x), "v"(x1.x)); }
-#endif
             c = blas_node_eval_ptr(q0, q1, q2, q3, R, best.t, spp);
           }
         } else if (c < 0 && c != kBlasDone) {
