@@ -388,3 +388,49 @@ def test_round1_fault_configurations(gpu_ctx, mode):
         ref = oracle_for(sc2).render(mode=1, threads=8)
         gpu, _, _ = render_gpu(gpu_ctx, sc2, mode)
         assert_same(gpu, ref, f"mixed scene, numBounces {b}, mode {mode}")
+
+
+@pytest.mark.parametrize("mode", [0, 2, 3])
+def test_object_level_cull_on_the_gpu(gpu_ctx, mode):
+    """The object-level cull (include/urt_math.h tlas_cull) through every walk that has it — the literal heap walk of the per-pixel and
+    persistent kernels, the listed / masked object-level phase of the default kernel: pixels == the oracle's LITERAL brute force (mode 0:
+    every popped object is intersected, as the reference does), pixels and traversal counters == the oracle's culled BVH mode, and the
+    cull really skips work (fewer triangle tests than with front_cull = 0).  Then the GPU verification pass (csrc/cullflags.hip): with
+    one heap leaf's box shrunk so that its MeshObject pokes out, that leaf is never culled — counters again equal the oracle, whose
+    restated rule clears the same flag — and the pixels still equal the literal brute force."""
+    sc = scenes.CONFIGS["C4"](96, 54, slices=14, stacks=11)
+    o = oracle_for(sc)
+    assert o.cull_flags().all()
+    lit = o.render(mode=0, threads=8)
+    ref, oc = o.render(mode=1, threads=8, counters=True)
+    gpu, _, gc = render_gpu(gpu_ctx, sc, mode, count=True)
+    assert_same(gpu, lit, f"C4-small mode {mode} vs the literal brute force")
+    assert_same(gpu, ref, f"C4-small mode {mode}")
+    for k in ("rays", "tlas_nodes", "blas_nodes", "tri_tests", "hit_tri", "hit_ground", "hit_sky"):
+        assert gc[k] == oc[k], (k, gc[k], oc[k])
+    gpu_ctx.set_option("front_cull", 0)
+    try:
+        gpu0, _, gc0 = render_gpu(gpu_ctx, sc, mode, count=True)
+    finally:
+        gpu_ctx.set_option("front_cull", 1)
+    assert_same(gpu0, lit, "front_cull = 0")
+    o.set_cull(False)
+    _, oc0 = o.render(mode=1, threads=8, counters=True)
+    assert gc0["tri_tests"] == oc0["tri_tests"] and gc0["blas_nodes"] == oc0["blas_nodes"]
+    assert gc["tri_tests"] < 0.6 * gc0["tri_tests"], (gc["tri_tests"], gc0["tri_tests"])
+    # a leaf whose box does not contain its object
+    bad = sc.mesh_bvh.copy()
+    leaf = [i for i in range(len(bad)) if bad[i]["index"] >= 0][3]
+    bad[leaf]["vmax"] = bad[leaf]["vmin"] + (bad[leaf]["vmax"] - bad[leaf]["vmin"]) * 0.5
+    sc2 = copy.copy(sc)
+    sc2.mesh_bvh = bad
+    o2 = oracle_for(sc2)
+    f2 = o2.cull_flags()
+    assert f2[bad[leaf]["index"]] == 0 and f2.sum() == len(f2) - 1
+    lit2 = o2.render(mode=0, threads=8)
+    ref2, oc2 = o2.render(mode=1, threads=8, counters=True)
+    gpu2, _, gc2 = render_gpu(gpu_ctx, sc2, mode, count=True)
+    assert_same(gpu2, lit2, "shrunk leaf box vs the literal brute force")
+    assert_same(gpu2, ref2, "shrunk leaf box")
+    for k in ("tlas_nodes", "blas_nodes", "tri_tests"):
+        assert gc2[k] == oc2[k], (k, gc2[k], oc2[k])
