@@ -1,5 +1,8 @@
-"""Extended randomised parity run (GPU vs the oracle on its OWN BVH, bit for bit): the generator of tests/test_gpu_fuzz.py over many
-more seeds and every kernel mode.  usage: python scripts/fuzz_extended.py [first_seed] [count]"""
+"""Extended randomised parity run (GPU vs the oracle, bit for bit): the generator of tests/test_gpu_fuzz.py over many more seeds, every
+kernel mode and all three triangle-BVH builders.  Even scenes: the oracle walks its OWN BVH (with the product's object-level cull
+restated); odd scenes: the oracle's LITERAL brute force (every triangle of every object the reference would intersect, no cull at
+all) — so the product's cull and BVH are checked against the reference's semantics directly.
+usage: python scripts/fuzz_extended.py [first_seed] [count]"""
 import sys, time
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import numpy as np
@@ -17,6 +20,7 @@ for k in range(count):
     seed = first + k
     sc, builder, frames = random_scene(seed)
     mode = (3, 3, 3, 0, 2, 4, 5, 1)[k % 8]
+    if builder == 1 and (k // 8) % 2: builder = 2             # the depth-budgeted GPU builder takes every other turn of the GPU-built scenes
     ctx.set_option("kernel_mode", mode); ctx.set_option("blas_builder", builder)
     m = RayTraceMaster(ctx, sc)
     for _ in range(frames): m.OnRenderImage()
@@ -27,7 +31,7 @@ for k in range(count):
     omode = 0
     if len(sc.mesh_objects):
         nodes, _, _ = o.build_own_blas()
-        omode = 1 if len(nodes) else 0                      # (only single-leaf MeshObjects: no nodes to hand over — brute force)
+        omode = 1 if len(nodes) and k % 2 == 0 else 0       # odd scenes (and scenes of single-leaf MeshObjects only): the literal brute force
     acc = np.zeros((sc.height, sc.width, 4), np.float32)
     for i in range(frames):
         ox, oy, sd = scenes.frame_uniforms(i)
