@@ -1,4 +1,4 @@
-// UrtNative.cs — P/Invoke declarations for libunityraytracer_amd.so (include/urt.h, ABI version 2).
+// UrtNative.cs — P/Invoke declarations for libunityraytracer_amd.so (include/urt.h, ABI version 4; a negative urt_abi_version() = an experiment build: refuse it).
 // Drop into Assets/Scripts/ of RemyMuj/UnityRayTracer next to RayTraceMaster.cs ("RM"); the native library goes to
 // Assets/Plugins/x86_64/libunityraytracer_amd.so.  One declaration per exported entry point, in the header's order; each
 // group cites the RM call site it stands in for.  SOURCE ONLY: the build image of this repository has no C#/.NET/Mono
