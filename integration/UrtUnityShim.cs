@@ -19,6 +19,8 @@ public static class UrtDevice {
     internal static IntPtr Handle { get { Ensure(); return group != IntPtr.Zero ? group : ctx; } }
     static void Ensure() {
         if (ctx != IntPtr.Zero || group != IntPtr.Zero) return;
+        // a negative ABI version marks an A/B / probe / diagnostic BUILD of the library (csrc/experiments.h): never the product
+        if (UrtNative.urt_abi_version() < 0) throw new InvalidOperationException("libunityraytracer_amd is an experiment build (negative urt_abi_version): refused");
         if (Devices.Length > 1) UrtNative.CheckGroup(IntPtr.Zero, UrtNative.urt_group_create(Devices, Devices.Length, out group));
         else UrtNative.Check(IntPtr.Zero, UrtNative.urt_context_create(Devices[0], out ctx));
     }
