@@ -189,8 +189,13 @@ def main():
         slot_alpha = {}
 
         def mean_alpha(sample):
+            """alpha of the running mean after samples 0..sample (one blend step per new sample: the table grows with the run)"""
             if sample not in alpha_of:
-                alpha_of[sample] = strips.running_mean_alpha(range(sample + 1))
+                last = max((k for k in alpha_of if k < sample), default=-1)
+                w = alpha_of.get(last, 0.0)
+                for k in range(last + 1, sample + 1):
+                    w = strips.running_mean_alpha([k], start=w)
+                    alpha_of[k] = w
             return alpha_of[sample]
         ring = 2 * burst
         packed = [torch.zeros(n_floats, dtype=torch.float32, device=device) for _ in range(ring)]

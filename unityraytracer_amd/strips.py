@@ -59,11 +59,11 @@ def gather_to_root(dist, mine, rank: int, world: int):
     return parts
 
 
-def running_mean_alpha(samples) -> float:
+def running_mean_alpha(samples, start: float = 0.0) -> float:
     """Alpha channel of `_converged` after AdditionShader blends with _Sample = s for s in `samples` (in order), starting from a fresh
     (zero) image: the fragment's alpha is a = 1 / (s + 1) itself and is blended like the colours (AS:39-41), so every pixel holds
     w <- a * a + w * (1 - a) in float32 — exactly the operations of k_blit_add.  What the root passes to urt_texture_unpack_rows_rgb."""
-    w = np.float32(0.0)
+    w = np.float32(start)                                     # (`start`: the alpha the image held before these samples)
     one = np.float32(1.0)
     for s in samples:
         a = one / (np.float32(s) + one)
