@@ -391,7 +391,8 @@ def main():
             hbm = {"achieved": round(traffic / (launch_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                    "frac": round(traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "bytes_per_launch": traffic,
                    "over_algorithmic": round(traffic / max(1.0, alg), 3)}
-        common = {"kernel": kname, "kernel_mode": linfo["kernel_mode"], "launch_ms": round(launch_ms, 4), "frames_per_launch": round(frames_per_launch, 2),
+        common = {"algorithmic_frac": algorithmic["frac_of_hbm_peak"],     # SURVEY 8(d)'s byte fraction — saturates (> 1 possible): a work rate, see `algorithmic`
+                  "kernel": kname, "kernel_mode": linfo["kernel_mode"], "launch_ms": round(launch_ms, 4), "frames_per_launch": round(frames_per_launch, 2),
                   "kernel_ms_per_frame": round(kernel_ms, 4), "traffic": traffic, "traffic_source": traffic_source, "hbm": hbm, "algorithmic": algorithmic,
                   "launch": {k: linfo[k] for k in ("front_mode", "n_blocks", "block_threads", "lds_bytes", "waves_per_cu", "xcd_run", "frame_group", "top_nodes", "slab_frames_max")}}
         if valu_insts:
