@@ -181,7 +181,9 @@ typedef struct urt_counters {
  *                          of milliseconds for scenes whose objects move; 2 = the same radix tree built top-down within a depth
  *                          budget ("lbvh_slack", default 6 levels beyond a median tree): the traversal stacks live in LDS and a
  *                          30-level Karras tree costs workgroups per CU — frames on tree 2 cost +6 ... +10 % against the SAH trees
- *                          instead of +10 ... +26 %, the build 1 ms more on a million triangles; same pixels whichever builder),
+ *                          instead of +10 ... +26 %, the build 1 ms more on a million triangles; 3 = BINNED SAH ON THE GPU — the host builder's
+ *                          algorithm level by level with atomics: frames as on the host's trees, 15 ms instead of 80 for a million
+ *                          triangles; same pixels whichever builder),
  *          "front_cull" (0/1, default 1: object-level cull — a MeshObject whose heap-leaf box the ray passes, leaves behind or meets
  *                        beyond the ground-plane hit, by a margin, is not intersected although the reference would (RS:294-326 keeps
  *                        testing every popped leaf once `tests` is set; such an object cannot hold the closest hit).  Only leaves whose

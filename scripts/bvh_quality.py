@@ -13,7 +13,7 @@ def area(lo, hi):
 ctx = Context(0)
 for cfg in sys.argv[1:] or ["C3", "C3D", "C4", "C5"]:
     sc = scenes.CONFIGS[cfg]()
-    for builder in (0, 1, 2):
+    for builder in (0, 1, 2, 3):
         ctx.set_option("blas_builder", builder)
         ctx.set_option("count_stats", 1)
         m = RayTraceMaster(ctx, sc)

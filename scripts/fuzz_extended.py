@@ -20,7 +20,7 @@ for k in range(count):
     seed = first + k
     sc, builder, frames = random_scene(seed)
     mode = (3, 3, 3, 0, 2, 4, 5, 1)[k % 8]
-    if builder == 1 and (k // 8) % 2: builder = 2             # the depth-budgeted GPU builder takes every other turn of the GPU-built scenes
+    if builder == 1: builder = (1, 2, 3)[(k // 8) % 3]        # the three GPU builders take turns (Karras tree, depth-budgeted tree, binned SAH)
     ctx.set_option("kernel_mode", mode); ctx.set_option("blas_builder", builder)
     m = RayTraceMaster(ctx, sc)
     for _ in range(frames): m.OnRenderImage()

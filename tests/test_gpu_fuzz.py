@@ -56,6 +56,8 @@ def random_scene(seed):
 @pytest.mark.parametrize("seed", range(16))
 def test_random_scene_bit_exact(gpu_ctx, seed):
     sc, builder, frames = random_scene(1000 + seed)
+    if builder == 1:
+        builder = (1, 2, 3)[seed % 3]                          # the three GPU builders take turns: Karras tree, depth-budgeted tree, binned SAH
     gpu_ctx.set_option("kernel_mode", 3)
     gpu_ctx.set_option("blas_builder", builder)
     try:

@@ -16,7 +16,7 @@ def bits_equal(a, b):
     return np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
-@pytest.fixture(params=[1, 2], ids=["karras", "budget"])
+@pytest.fixture(params=[1, 2, 3], ids=["karras", "budget", "sah"])
 def lbvh(gpu_ctx, request):
     """Both GPU builders: 1 = the Morton radix tree as built, 2 = the same radix tree built top-down within a depth budget (csrc/lbvh.hip k_td_level)."""
     gpu_ctx.set_option("kernel_mode", 3)
@@ -59,7 +59,7 @@ def test_gpu_built_tree_is_valid_and_top_is_breadth_first(lbvh, scene_fn):
     assert len(seen) == len(nodes) - len(roots)                               # every non-root node has exactly one parent
 
 
-@pytest.mark.parametrize("builder", [1, 2])
+@pytest.mark.parametrize("builder", [1, 2, 3])
 @pytest.mark.parametrize("scene_fn", [lambda: scenes.mixed_test_scene(160, 96), lambda: scenes.many_meshes_scene(128, 80, n=120, level=0)])
 def test_frames_equal_host_built_tree_and_oracle(gpu_ctx, scene_fn, builder):
     sc = scene_fn()
@@ -123,7 +123,7 @@ def test_bad_index_is_reported_like_the_host_builder(lbvh):
     m.OnDisable()
 
 
-@pytest.mark.parametrize("builder,limit_ms", [(1, 10.0), (2, 24.0)])
+@pytest.mark.parametrize("builder,limit_ms", [(1, 10.0), (2, 24.0), (3, 24.0)])
 def test_c5_scene_preparation_under_10_ms(gpu_ctx, builder, limit_ms):
     """983,040 triangles in 12 MeshObjects: upload of the raw buffers + the whole GPU build, host wall clock (builder 2 — one launch
     per tree level — may take twice the 12 ms the Karras tree needs to its first frame: VERDICT round 3, item 6)."""

@@ -60,7 +60,7 @@ def fresh_frame(ctx, sc, builder=0):
     return img
 
 
-@pytest.mark.parametrize("builder", [0, 1])
+@pytest.mark.parametrize("builder", [0, 1, 3])
 def test_moved_meshes_are_refitted_not_rebuilt(gpu_ctx, other_ctx, builder):
     gpu_ctx.set_option("kernel_mode", 3)
     gpu_ctx.set_option("blas_builder", builder)

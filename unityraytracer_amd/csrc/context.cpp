@@ -648,7 +648,7 @@ int prepare_scene(urt_context* ctx) {
       in.vertices = bv ? (const float*)(rb + b_mo) : nullptr; in.n_vertices = bv ? bv->count : 0;
       in.indices = bi ? (const int32_t*)(rb + b_mo + b_v) : nullptr; in.n_indices = bi ? bi->count : 0;
       in.normals = bn ? (const float*)(rb + b_mo + b_v + b_i) : nullptr; in.n_normals = bn ? bn->count : 0;
-      in.h_offsets = offs.data(); in.h_counts = cnts.data(); in.leaf_max = get_blas_leaf_max(); in.depth_budget = ctx->opt_blas_builder == 2; in.depth_slack = ctx->opt_lbvh_slack;
+      in.h_offsets = offs.data(); in.h_counts = cnts.data(); in.leaf_max = get_blas_leaf_max(); in.depth_budget = ctx->opt_blas_builder == 2; in.depth_slack = ctx->opt_lbvh_slack; in.sah = ctx->opt_blas_builder == 3;
       LbvhOutput o;
       std::string err;
       rc = lbvh_build(in, ctx->stream, o, err);
@@ -1757,7 +1757,7 @@ int urt_set_option(urt_context* ctx, const char* name, int value) {
   if (!name) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "option name is NULL");
   { (void)hipSetDevice(ctx->device); int rc = flush_pending(ctx); if (rc) return rc; }   // deferred frames run with the options they were dispatched under
   if (std::strcmp(name, "blas_builder") == 0) {
-    if (value < 0 || value > 2) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "blas_builder must be 0 (host SAH), 1 (GPU LBVH) or 2 (GPU LBVH built top-down within a depth budget)");
+    if (value < 0 || value > 3) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "blas_builder must be 0 (host SAH), 1 (GPU LBVH), 2 (GPU LBVH built top-down within a depth budget) or 3 (binned SAH on the GPU)");
     if (value != ctx->opt_blas_builder) { ctx->scene_dirty = true; ctx->dirty_full = true; }
     ctx->opt_blas_builder = value;
   } else if (std::strcmp(name, "frames_per_launch") == 0) {

@@ -16,6 +16,7 @@ struct LbvhInput {
   // HOST copies of each MeshObject's (indices_offset, indices_count): they lay out the per-mesh segments
   const int32_t* h_offsets = nullptr; const int32_t* h_counts = nullptr;
   int leaf_max = 2;                                             // triangles per leaf (1..8)
+  bool sah = false;                                             // builder 3: binned SAH on the GPU, level by level (lbvh.hip k_sah_*): the host builder's algorithm
   int depth_slack = 6;                                          // builder 2: levels beyond a median tree of the biggest MeshObject that lopsided radix splits may use
   bool depth_budget = false;                                    // builder 2: the radix tree built top-down, lopsided splits halved once the depth budget would be exceeded (lbvh.hip k_td_level)
 };

@@ -65,6 +65,16 @@ struct Dev {
   int* root_id;                          // [n_meshes] internal-node index of the MeshObject's root (Karras: the first position of its segment)
   int4* tdq[2];                          // top-down builder (2): this level's and the next level's ranges {a, b, parent, side | depth << 1}
   int depth_cap;                         // top-down builder: deepest level a leaf may sit on
+  // ---- builder 3: binned SAH on the GPU, level by level (k_sah_*) ----
+  unsigned int* sidx[2];                 // [T] x 2 (ping-pong): triangle id at position p
+  int* snode[2];                         // [T] x 2: index of the position's node in the level's list, or -1 (its leaf is final)
+  int* sflag; int* sscan;                // [T] left-side flags of the level and their exclusive scan
+  int4* sl_rng[2];                       // level node lists (ping-pong): {first, end, parent final id (-1 - mesh for a root), side | nb << 1}
+  uint4* sl_cb0[2]; uint2* sl_cb1[2];    //   centroid bounds as order-preserving uints: {lo.x, lo.y, lo.z, hi.x}, {hi.y, hi.z}
+  int* sl_binoff[2];                     //   first word of the node's bins
+  int4* sl_dec;                          // this level's decisions: {axis (-1: halve by position), bin, n_left, child-node count}
+  int* sl_cnt; int* sl_cscan; int* sl_words; int* sl_wscan;     // per node: child nodes / bin words of the next level, and their scans
+  unsigned int* sbins;                   // bins: per (node, axis, bin) 7 words {count, lo.xyz, hi.xyz (ordered uints)}
   float4* nodes; float4* tri_verts; float4* tri_norms;      // out
 };
 
@@ -408,6 +418,286 @@ __global__ __launch_bounds__(256) void k_emit_tris(Dev D) {
   }
 }
 
+
+// =====================================================================================================================================
+// builder 3: BINNED SAH ON THE GPU.  The host builder's algorithm (blas_builder.cpp Builder::build: per range the centroid bounds, 32
+// bins per axis over them, the cheapest of the 3 x 31 planes by A(L) n_L + A(R) n_R, halving by position when no plane separates)
+// run level by level over all MeshObjects at once: one pass bins every triangle of the level into its node's bins with atomics (ordered-
+// uint min / max), one thread per node sweeps the bins and picks the plane, a flag + scan + scatter pass partitions the ranges in place
+// (stable), and the scatter pass also gathers the children's centroid bounds for the next level.  Nodes are numbered level by level —
+// which IS the breadth-first top-of-forest order the trace kernel keeps in LDS.  Nodes of fewer than 64 triangles use 8 bins per axis
+// (they cannot fill more), which bounds the bin memory by 72 words per triangle.
+// =====================================================================================================================================
+constexpr int kSahBinsBig = 32, kSahBinsSmall = 8, kSahBigNode = 64;
+__device__ __forceinline__ int sah_nb(int size) { return size >= kSahBigNode ? kSahBinsBig : kSahBinsSmall; }
+__device__ __forceinline__ float3 tri_centroid(const Dev& D, unsigned int g) {
+  float4 lo = D.tlo[g], hi = D.thi[g];
+  return make_float3(0.5f * lo.x + 0.5f * hi.x, 0.5f * lo.y + 0.5f * hi.y, 0.5f * lo.z + 0.5f * hi.z);
+}
+__device__ __forceinline__ int sah_bin(float c, float lo, float ext, int nb) {       // blas_builder.cpp: (int)((c - lo) * (bins / ext)), clamped
+  int b = (int)((c - lo) * ((float)nb / ext));
+  return min(max(b, 0), nb - 1);
+}
+
+__global__ __launch_bounds__(64) void k_sah_roots(Dev D) {        // one lane: level 0 = the MeshObjects that need a tree, in MeshObject order
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int n = 0, words = 0;
+  for (int m = 0; m < D.n_meshes; m++) {
+    int lo = D.tri_first[m], size = D.tri_first[m + 1] - lo;
+    if (size <= 0) continue;
+    if (size <= D.leaf_max) { D.mesh_root[m] = leaf_code(lo, size); atomicMax(D.scalars + 1, 1); continue; }
+    int nb = sah_nb(size);
+    D.sl_rng[0][n] = make_int4(lo, lo + size, -1 - m, nb << 1);
+    MeshStat s = D.stats[m];
+    D.sl_cb0[0][n] = make_uint4(s.cmin[0], s.cmin[1], s.cmin[2], s.cmax[0]);
+    D.sl_cb1[0][n] = make_uint2(s.cmax[1], s.cmax[2]);
+    D.sl_binoff[0][n] = words;
+    words += 3 * nb * 7;
+    D.mesh_root[m] = n;                                       // level 0 starts at node 0
+    n++;
+  }
+  D.scalars[3] = n; D.scalars[2] = words;
+}
+
+__global__ __launch_bounds__(256) void k_sah_positions(Dev D) {   // level 0: identity order, every position belongs to its MeshObject's root
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= D.T) return;
+  D.sidx[0][p] = (unsigned int)p;
+  int m = find_mesh(D.tri_first, D.n_meshes, p);
+  int size = D.tri_first[m + 1] - D.tri_first[m];
+  D.snode[0][p] = size > D.leaf_max ? D.mesh_root[m] : -1;
+}
+
+__global__ __launch_bounds__(256) void k_sah_bins_init(Dev D, int words) {
+  int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= words) return;
+  int k = w % 7;
+  D.sbins[w] = k == 0 ? 0u : (k <= 3 ? 0xffffffffu : 0u);     // count, lo (ordered +max), hi (ordered min)
+}
+
+// Binning.  The positions of a node are contiguous, so a workgroup whose first and last position belong to one node bins into a
+// private copy in LDS and merges its non-empty bins into the node's with one atomic per word (near the root that is 8x fewer global
+// atomics, and none of the same-address pile-ups: a level of C5 took 1.6 ms with per-lane atomics); workgroups that straddle
+// nodes (deep levels: many small nodes, little contention) use the global atomics directly.
+__global__ __launch_bounds__(256) void k_sah_bin(Dev D, int src) {
+  __shared__ unsigned int sb[3 * kSahBinsBig * 7];
+  const int p0 = blockIdx.x * blockDim.x, p1 = min(p0 + (int)blockDim.x, D.T) - 1;
+  const int nd0 = D.snode[src][p0];
+  const bool uniform = nd0 >= 0 && D.snode[src][p1] == nd0;              // (workgroup-uniform)
+  int p = p0 + threadIdx.x;
+  int nd = p < D.T ? D.snode[src][p] : -1;
+  int nb_u = 0;
+  if (uniform) {
+    nb_u = D.sl_rng[src][nd0].w >> 1;
+    for (int w = threadIdx.x; w < 3 * nb_u * 7; w += blockDim.x) { int k = w % 7; sb[w] = k == 0 ? 0u : (k <= 3 ? 0xffffffffu : 0u); }
+    __syncthreads();
+  }
+  if (nd >= 0) {
+    unsigned int g = D.sidx[src][p];
+    float4 lo = D.tlo[g], hi = D.thi[g];
+    const float c[3] = {0.5f * lo.x + 0.5f * hi.x, 0.5f * lo.y + 0.5f * hi.y, 0.5f * lo.z + 0.5f * hi.z};
+    uint4 b0 = D.sl_cb0[src][nd]; uint2 b1 = D.sl_cb1[src][nd];
+    const float clo[3] = {ord2f(b0.x), ord2f(b0.y), ord2f(b0.z)}, chi[3] = {ord2f(b0.w), ord2f(b1.x), ord2f(b1.y)};
+    const int nb = D.sl_rng[src][nd].w >> 1;
+    unsigned int* B = uniform ? sb : D.sbins + D.sl_binoff[src][nd];
+    const unsigned int olo[3] = {f2ord(lo.x), f2ord(lo.y), f2ord(lo.z)}, ohi[3] = {f2ord(hi.x), f2ord(hi.y), f2ord(hi.z)};
+    for (int ax = 0; ax < 3; ax++) {
+      float ext = chi[ax] - clo[ax];
+      if (!(ext > 0.0f)) continue;
+      unsigned int* q = B + (ax * nb + sah_bin(c[ax], clo[ax], ext, nb)) * 7;
+      atomicAdd(q, 1u);
+      atomicMin(q + 1, olo[0]); atomicMin(q + 2, olo[1]); atomicMin(q + 3, olo[2]);
+      atomicMax(q + 4, ohi[0]); atomicMax(q + 5, ohi[1]); atomicMax(q + 6, ohi[2]);
+    }
+  }
+  if (uniform) {
+    __syncthreads();
+    unsigned int* G = D.sbins + D.sl_binoff[src][nd0];
+    for (int w = threadIdx.x; w < 3 * nb_u * 7; w += blockDim.x) {
+      const int k = w % 7;
+      const unsigned int v = sb[w];
+      if (k == 0) { if (v) atomicAdd(G + w, v); }
+      else if (k <= 3) { if (v != 0xffffffffu) atomicMin(G + w, v); }
+      else if (v != 0u) atomicMax(G + w, v);
+    }
+  }
+}
+
+struct SBox { float lo[3], hi[3]; };
+__device__ __forceinline__ void sbox_reset(SBox& b) { for (int k = 0; k < 3; k++) { b.lo[k] = URT_INF; b.hi[k] = -URT_INF; } }
+__device__ __forceinline__ void sbox_grow(SBox& b, const unsigned int* q) {
+  for (int k = 0; k < 3; k++) { b.lo[k] = f_min(b.lo[k], ord2f(q[1 + k])); b.hi[k] = f_max(b.hi[k], ord2f(q[4 + k])); }
+}
+__device__ __forceinline__ float sbox_half_area(const SBox& b) {
+  float d0 = b.hi[0] - b.lo[0], d1 = b.hi[1] - b.lo[1], d2 = b.hi[2] - b.lo[2];
+  return d0 * d1 + d1 * d2 + d2 * d0;
+}
+
+// one thread per node of the level: the sweep of blas_builder.cpp (right-to-left suffix areas, left-to-right costs, first strict minimum over
+// axes 0, 1, 2), the sizes of the two sides, how many of them need a node of their own, and the bin words those will take
+__global__ __launch_bounds__(64) void k_sah_eval(Dev D, int src, int n_nodes) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_nodes) return;
+  int4 rg = D.sl_rng[src][i];
+  const int size = rg.y - rg.x, nb = rg.w >> 1;
+  uint4 b0 = D.sl_cb0[src][i]; uint2 b1 = D.sl_cb1[src][i];
+  const float clo[3] = {ord2f(b0.x), ord2f(b0.y), ord2f(b0.z)}, chi[3] = {ord2f(b0.w), ord2f(b1.x), ord2f(b1.y)};
+  const unsigned int* B = D.sbins + D.sl_binoff[src][i];
+  int best_axis = -1, best_bin = -1, best_nl = 0;
+  float best_cost = URT_INF;
+  for (int ax = 0; ax < 3; ax++) {
+    if (!(chi[ax] - clo[ax] > 0.0f)) continue;
+    const unsigned int* A = B + ax * nb * 7;
+    float right_area[kSahBinsBig]; int right_cnt[kSahBinsBig];
+    SBox acc; sbox_reset(acc); int c = 0;
+    for (int b = nb - 1; b > 0; b--) { if (A[b * 7]) sbox_grow(acc, A + b * 7); c += (int)A[b * 7]; right_area[b] = sbox_half_area(acc); right_cnt[b] = c; }
+    sbox_reset(acc); c = 0;
+    for (int b = 0; b < nb - 1; b++) {
+      if (A[b * 7]) sbox_grow(acc, A + b * 7);
+      c += (int)A[b * 7];
+      if (c == 0 || right_cnt[b + 1] == 0) continue;
+      float cost = sbox_half_area(acc) * (float)c + right_area[b + 1] * (float)right_cnt[b + 1];
+      if (cost < best_cost) { best_cost = cost; best_axis = ax; best_bin = b; best_nl = c; }
+    }
+  }
+  int nl = best_nl;
+  if (best_axis < 0 || nl <= 0 || nl >= size) { best_axis = -1; nl = size / 2; }      // no plane separates: halve by the current order (keeps the tree finite)
+  const int nr = size - nl;
+  const int kids = (nl > D.leaf_max) + (nr > D.leaf_max);
+  D.sl_dec[i] = make_int4(best_axis, best_bin, nl, kids);
+  D.sl_cnt[i] = kids;
+  D.sl_words[i] = (nl > D.leaf_max ? 3 * sah_nb(nl) * 7 : 0) + (nr > D.leaf_max ? 3 * sah_nb(nr) * 7 : 0);
+}
+
+// the node records of the level (final ids level_base + i) and the next level's list
+__global__ __launch_bounds__(64) void k_sah_emit(Dev D, int src, int n_nodes, int level_base) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_nodes) return;
+  const int dst = src ^ 1;
+  int4 rg = D.sl_rng[src][i], dec = D.sl_dec[i];
+  const int a = rg.x, size = rg.y - rg.x, nb = rg.w >> 1, nl = dec.z, nr = size - nl;
+  const int m = (int)(D.keys_s[a] >> 32);                     // (keys_s: MeshObject of the position; filled by k_sah_positions' caller)
+  const float pad = __uint_as_float(D.stats[m].ext) * 1.52587890625e-5f + 1e-30f;
+  SBox bl, br; sbox_reset(bl); sbox_reset(br);
+  const unsigned int* B = D.sbins + D.sl_binoff[src][i];
+  if (dec.x >= 0) {
+    const unsigned int* A = B + dec.x * nb * 7;
+    for (int b = 0; b < nb; b++) if (A[b * 7]) sbox_grow(b <= dec.y ? bl : br, A + b * 7);
+  } else {
+    // halved by position: the bins (if any axis had an extent) give the whole range's box, used for both sides — loose but sound
+    uint4 b0 = D.sl_cb0[src][i]; uint2 b1 = D.sl_cb1[src][i];
+    const float clo[3] = {ord2f(b0.x), ord2f(b0.y), ord2f(b0.z)}, chi[3] = {ord2f(b0.w), ord2f(b1.x), ord2f(b1.y)};
+    bool any = false;
+    for (int ax = 0; ax < 3 && !any; ax++) if (chi[ax] - clo[ax] > 0.0f) { const unsigned int* A = B + ax * nb * 7; for (int b = 0; b < nb; b++) if (A[b * 7]) sbox_grow(bl, A + b * 7); any = true; }
+    if (!any) { float e = __uint_as_float(D.stats[m].ext); for (int k = 0; k < 3; k++) { bl.lo[k] = -e; bl.hi[k] = e; } }   // all centroids coincide: the MeshObject's extent
+    br = bl;
+  }
+  const int id = level_base + i;
+  const int next_base = level_base + n_nodes;
+  int kid = D.sl_cscan[i], wat = D.sl_wscan[i];
+  int32_t code[2];
+  const int ca[2] = {a, a + nl}, cs[2] = {nl, nr};
+  for (int k = 0; k < 2; k++) {
+    if (cs[k] <= D.leaf_max) { code[k] = leaf_code(ca[k], cs[k]); continue; }
+    const int cnb = sah_nb(cs[k]);
+    code[k] = next_base + kid;
+    D.sl_rng[dst][kid] = make_int4(ca[k], ca[k] + cs[k], id, k | (cnb << 1));
+    D.sl_cb0[dst][kid] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0u);      // gathered by the scatter pass
+    D.sl_cb1[dst][kid] = make_uint2(0u, 0u);
+    D.sl_binoff[dst][kid] = wat;
+    wat += 3 * cnb * 7; kid++;
+  }
+  float4* nd = D.nodes + 4 * (size_t)id;
+  nd[0] = make_float4(bl.lo[0] - pad, bl.lo[1] - pad, bl.lo[2] - pad, bl.hi[0] + pad);
+  nd[1] = make_float4(bl.hi[1] + pad, bl.hi[2] + pad, br.lo[0] - pad, br.lo[1] - pad);
+  nd[2] = make_float4(br.lo[2] - pad, br.hi[0] + pad, br.hi[1] + pad, br.hi[2] + pad);
+  nd[3] = make_float4(__int_as_float(code[0]), __int_as_float(code[1]), 0.0f, 0.0f);
+}
+
+__global__ __launch_bounds__(256) void k_sah_flag(Dev D, int src) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= D.T) return;
+  int nd = D.snode[src][p], f = 0;
+  if (nd >= 0) {
+    int4 rg = D.sl_rng[src][nd], dec = D.sl_dec[nd];
+    if (dec.x < 0) f = (p - rg.x) < dec.z ? 1 : 0;
+    else {
+      uint4 b0 = D.sl_cb0[src][nd]; uint2 b1 = D.sl_cb1[src][nd];
+      const float clo[3] = {ord2f(b0.x), ord2f(b0.y), ord2f(b0.z)}, chi[3] = {ord2f(b0.w), ord2f(b1.x), ord2f(b1.y)};
+      float3 c = tri_centroid(D, D.sidx[src][p]);
+      const float cc[3] = {c.x, c.y, c.z};
+      f = sah_bin(cc[dec.x], clo[dec.x], chi[dec.x] - clo[dec.x], rg.w >> 1) <= dec.y ? 1 : 0;
+    }
+  }
+  D.sflag[p] = f;
+}
+
+__global__ __launch_bounds__(256) void k_sah_scatter(Dev D, int src, int level_base, int n_nodes) {
+  // the next level's centroid bounds are gathered here: per workgroup in LDS when all its positions belong to one node (two children, twelve
+  // words — a million same-address atomics per level otherwise: 14 ms on C5's first level), per lane for workgroups that straddle nodes
+  __shared__ unsigned int scb[12];
+  const int p0 = blockIdx.x * blockDim.x, p1 = min(p0 + (int)blockDim.x, D.T) - 1;
+  const int nd0 = D.snode[src][p0];
+  const bool uniform = nd0 >= 0 && D.snode[src][p1] == nd0;
+  if (uniform) { if (threadIdx.x < 12) scb[threadIdx.x] = (threadIdx.x % 6) < 3 ? 0xffffffffu : 0u; __syncthreads(); }
+  const int p = p0 + threadIdx.x;
+  const int dst = src ^ 1;
+  int first_child = -1;
+  if (p < D.T) {
+    int nd = D.snode[src][p];
+    unsigned int g = D.sidx[src][p];
+    if (nd < 0) { D.sidx[dst][p] = g; D.snode[dst][p] = -1; }
+    else {
+      int4 rg = D.sl_rng[src][nd], dec = D.sl_dec[nd];
+      const int a = rg.x, nl = dec.z, nr = (rg.y - rg.x) - nl;
+      const int rank = D.sscan[p] - D.sscan[a];                   // left-side positions of this node before p
+      const bool left = D.sflag[p] != 0;
+      const int np = left ? a + rank : a + nl + ((p - a) - rank);
+      // the side's index in the next level's list, as k_sah_emit numbers it
+      first_child = D.sl_cscan[nd];
+      int child = -1;
+      if (left) { if (nl > D.leaf_max) child = first_child; }
+      else if (nr > D.leaf_max) child = first_child + (nl > D.leaf_max ? 1 : 0);
+      D.sidx[dst][np] = g;
+      D.snode[dst][np] = child;
+      if (child >= 0) {                                           // the next level's centroid bounds
+        float3 c = tri_centroid(D, g);
+        unsigned int ox = f2ord(c.x), oy = f2ord(c.y), oz = f2ord(c.z);
+        unsigned int *qlo, *qhi0, *qhi1;
+        if (uniform) { unsigned int* q = scb + 6 * (child - first_child); qlo = q; qhi0 = q + 3; qhi1 = q + 4; }
+        else { unsigned int* q0 = (unsigned int*)&D.sl_cb0[dst][child]; qlo = q0; qhi0 = q0 + 3; qhi1 = (unsigned int*)&D.sl_cb1[dst][child]; }
+        if (c.x == c.x) { atomicMin(qlo, ox); atomicMax(qhi0, ox); }
+        if (c.y == c.y) { atomicMin(qlo + 1, oy); atomicMax(qhi1, oy); }
+        if (c.z == c.z) { atomicMin(qlo + 2, oz); atomicMax(qhi1 + 1, oz); }
+      }
+    }
+  }
+  if (uniform) {
+    __syncthreads();
+    if (threadIdx.x < 12) {
+      const int k = threadIdx.x / 6, w = threadIdx.x % 6;
+      int4 dec = D.sl_dec[nd0];
+      const int kids = dec.w, child = D.sl_cscan[nd0] + k;
+      const unsigned int v = scb[threadIdx.x];
+      if (k < kids) {
+        unsigned int* q0 = (unsigned int*)&D.sl_cb0[dst][child]; unsigned int* q1 = (unsigned int*)&D.sl_cb1[dst][child];
+        unsigned int* q = w < 4 ? q0 + w : q1 + (w - 4);
+        if (w < 3) { if (v != 0xffffffffu) atomicMin(q, v); } else if (v != 0u) atomicMax(q, v);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_sah_finish(Dev D, int src) {     // final order -> vals_s (what k_emit_tris reads)
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < D.T) D.vals_s[p] = D.sidx[src][p];
+}
+
+__global__ __launch_bounds__(256) void k_sah_keys(Dev D) {                 // keys_s[p] = MeshObject of position p (positions never leave their MeshObject's segment)
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < D.T) D.keys_s[p] = (unsigned long long)(unsigned int)find_mesh(D.tri_first, D.n_meshes, p) << 32;
+}
+
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 }  // namespace
@@ -479,6 +769,20 @@ int lbvh_build(const LbvhInput& in, hipStream_t st, LbvhOutput& out, std::string
   const size_t o_stats = carve(sizeof(MeshStat) * (size_t)kStatShards * (size_t)nm);
   const size_t o_scalars = carve(64);
   const size_t o_root_id = carve(4 * (size_t)nm);
+  // builder 3 (GPU binned SAH)
+  const size_t LN = in.sah ? (size_t)T / 2 + (size_t)nm + 2 : 0;          // most nodes a level can have (every node has > leaf_max >= 1 triangles)
+  size_t o_sidx[2] = {0, 0}, o_snode[2] = {0, 0}, o_sflag = 0, o_sscan = 0, o_slrng[2] = {0, 0}, o_slcb0[2] = {0, 0}, o_slcb1[2] = {0, 0}, o_slbo[2] = {0, 0};
+  size_t o_sldec = 0, o_slcnt = 0, o_slcscan = 0, o_slwords = 0, o_slwscan = 0, o_sbins = 0;
+  const size_t bin_words = in.sah ? 72 * (size_t)T + 4096 : 0;
+  if (in.sah) {
+    for (int k = 0; k < 2; k++) {
+      o_sidx[k] = carve(4 * (size_t)T); o_snode[k] = carve(4 * (size_t)T);
+      o_slrng[k] = carve(16 * LN); o_slcb0[k] = carve(16 * LN); o_slcb1[k] = carve(8 * LN); o_slbo[k] = carve(4 * LN);
+    }
+    o_sflag = carve(4 * (size_t)T); o_sscan = carve(4 * (size_t)T);
+    o_sldec = carve(16 * LN); o_slcnt = carve(4 * LN); o_slcscan = carve(4 * LN); o_slwords = carve(4 * LN); o_slwscan = carve(4 * LN);
+    o_sbins = carve(4 * bin_words);
+  }
   const size_t o_tdq0 = in.depth_budget ? carve(sizeof(int4) * (size_t)T) : 0, o_tdq1 = in.depth_budget ? carve(sizeof(int4) * (size_t)T) : 0;
   const size_t o_sort = carve(sort_bytes), o_scan = carve(scan_bytes);
   LBVH_HIP(hipMalloc(&temp, at));
@@ -501,6 +805,15 @@ int lbvh_build(const LbvhInput& in, hipStream_t st, LbvhOutput& out, std::string
   D.mesh_root = out.mesh_root;
   D.scalars = (int*)(base + o_scalars);
   D.root_id = (int*)(base + o_root_id);
+  if (in.sah) {
+    for (int k = 0; k < 2; k++) {
+      D.sidx[k] = (unsigned int*)(base + o_sidx[k]); D.snode[k] = (int*)(base + o_snode[k]);
+      D.sl_rng[k] = (int4*)(base + o_slrng[k]); D.sl_cb0[k] = (uint4*)(base + o_slcb0[k]); D.sl_cb1[k] = (uint2*)(base + o_slcb1[k]); D.sl_binoff[k] = (int*)(base + o_slbo[k]);
+    }
+    D.sflag = (int*)(base + o_sflag); D.sscan = (int*)(base + o_sscan);
+    D.sl_dec = (int4*)(base + o_sldec); D.sl_cnt = (int*)(base + o_slcnt); D.sl_cscan = (int*)(base + o_slcscan); D.sl_words = (int*)(base + o_slwords); D.sl_wscan = (int*)(base + o_slwscan);
+    D.sbins = (unsigned int*)(base + o_sbins);
+  }
   D.tdq[0] = (int4*)(base + o_tdq0); D.tdq[1] = (int4*)(base + o_tdq1);
   {   // depth budget of the top-down builder: what a median tree of the biggest MeshObject needs, + 6 levels of slack for lopsided radix splits
     int biggest = 1;
@@ -519,6 +832,43 @@ int lbvh_build(const LbvhInput& in, hipStream_t st, LbvhOutput& out, std::string
   hipLaunchKernelGGL(k_init, dim3(gi), dim3(256), 0, st, D);
   hipLaunchKernelGGL(k_tri_bounds, dim3(gb), dim3(256), 0, st, D);
   hipLaunchKernelGGL(k_fold_stats, dim3((unsigned int)((nm + 63) / 64)), dim3(64), 0, st, D);
+  int sah_nodes = -1, sah_levels = 0;
+  if (in.sah) {
+    // ---- builder 3: binned SAH, level by level ----
+    auto scan = [&](int* in_, int* out_, size_t n) { return rocprim::exclusive_scan(base + o_scan, scan_bytes, in_, out_, 0, n, rocprim::plus<int>(), st); };
+    auto blocks = [](size_t n, int per) { return dim3((unsigned int)((std::max<size_t>(n, 1) + (size_t)per - 1) / (size_t)per)); };
+    hipLaunchKernelGGL(k_sah_keys, dim3(gb), dim3(256), 0, st, D);
+    hipLaunchKernelGGL(k_sah_roots, dim3(1), dim3(64), 0, st, D);
+    hipLaunchKernelGGL(k_sah_positions, dim3(gb), dim3(256), 0, st, D);
+    int sc[4] = {0, 0, 0, 0};
+    LBVH_HIP(hipMemcpyAsync(sc, D.scalars, sizeof sc, hipMemcpyDeviceToHost, st));
+    LBVH_HIP(hipStreamSynchronize(st));
+    size_t n = (size_t)sc[3], words = (size_t)sc[2];
+    int src = 0, level_base = 0;
+    while (n > 0) {
+      if (n > LN || words > bin_words || sah_levels >= 120) { err = "GPU SAH builder: level " + std::to_string(sah_levels) + " does not fit its buffers"; if (temp) (void)hipFree(temp); for (void* q : out.allocs) (void)hipFree(q); out = LbvhOutput(); return URT_ERR_SCENE; }
+      hipLaunchKernelGGL(k_sah_bins_init, blocks(words, 256), dim3(256), 0, st, D, (int)words);
+      hipLaunchKernelGGL(k_sah_bin, dim3(gb), dim3(256), 0, st, D, src);
+      hipLaunchKernelGGL(k_sah_eval, blocks(n, 64), dim3(64), 0, st, D, src, (int)n);
+      LBVH_HIP(scan(D.sl_cnt, D.sl_cscan, n));
+      LBVH_HIP(scan(D.sl_words, D.sl_wscan, n));
+      hipLaunchKernelGGL(k_sah_emit, blocks(n, 64), dim3(64), 0, st, D, src, (int)n, level_base);
+      hipLaunchKernelGGL(k_sah_flag, dim3(gb), dim3(256), 0, st, D, src);
+      LBVH_HIP(scan(D.sflag, D.sscan, (size_t)T));
+      hipLaunchKernelGGL(k_sah_scatter, dim3(gb), dim3(256), 0, st, D, src, level_base, (int)n);
+      int t4[4] = {0, 0, 0, 0};
+      LBVH_HIP(hipMemcpyAsync(&t4[0], D.sl_cscan + (n - 1), sizeof(int), hipMemcpyDeviceToHost, st));
+      LBVH_HIP(hipMemcpyAsync(&t4[1], D.sl_cnt + (n - 1), sizeof(int), hipMemcpyDeviceToHost, st));
+      LBVH_HIP(hipMemcpyAsync(&t4[2], D.sl_wscan + (n - 1), sizeof(int), hipMemcpyDeviceToHost, st));
+      LBVH_HIP(hipMemcpyAsync(&t4[3], D.sl_words + (n - 1), sizeof(int), hipMemcpyDeviceToHost, st));
+      LBVH_HIP(hipStreamSynchronize(st));
+      level_base += (int)n;
+      n = (size_t)(t4[0] + t4[1]); words = (size_t)(t4[2] + t4[3]);
+      src ^= 1; sah_levels++;
+    }
+    hipLaunchKernelGGL(k_sah_finish, dim3(gb), dim3(256), 0, st, D, src);
+    sah_nodes = level_base;
+  } else {
   hipLaunchKernelGGL(k_morton, dim3(gb), dim3(256), 0, st, D);
   LBVH_HIP(rocprim::radix_sort_pairs(base + o_sort, sort_bytes, D.keys, D.keys_s, D.vals, D.vals_s, (size_t)T, 0, 32 + mesh_bits, st));
   if (!in.depth_budget) {
@@ -542,6 +892,7 @@ int lbvh_build(const LbvhInput& in, hipStream_t st, LbvhOutput& out, std::string
   hipLaunchKernelGGL(k_flags, dim3(gb), dim3(256), 0, st, D);
   LBVH_HIP(rocprim::exclusive_scan(base + o_scan, scan_bytes, D.flag, D.rank, 0, (size_t)T, rocprim::plus<int>(), st));
   hipLaunchKernelGGL(k_emit_nodes, dim3(gb), dim3(256), 0, st, D);
+  }
   hipLaunchKernelGGL(k_emit_tris, dim3(gb), dim3(256), 0, st, D);
   LBVH_HIP(hipGetLastError());
   int scalars[4] = {0, 0, 0, 0}, last_rank = 0, last_flag = 0;
@@ -561,6 +912,7 @@ int lbvh_build(const LbvhInput& in, hipStream_t st, LbvhOutput& out, std::string
   }
   out.max_depth = scalars[1];
   out.n_nodes = scalars[2] + last_rank + last_flag;        // top of the forest + the compacted rest
+  if (sah_nodes >= 0) { out.n_nodes = sah_nodes; out.max_depth = std::max(scalars[1], sah_nodes > 0 ? sah_levels + 1 : 0); }
   return URT_OK;
 }
 
