@@ -1,6 +1,6 @@
 # Scene-preparation time (SetData -> ready device scene, host wall clock reported by the library) for the reference's dynamic-scene
 # protocol (RM:215-230: any move re-uploads EVERY buffer): nothing moved / one MeshObject moved / all moved, with the host SAH builder
-# (per-MeshObject BVH cache) and with the GPU LBVH builder.   python scripts/dynamic_scene.py [C4 C5]
+# (per-MeshObject BVH cache) and with the three GPU builders (1 Karras radix tree, 2 depth-budgeted radix tree, 3 binned SAH).   python scripts/dynamic_scene.py [C4 C5]
 import sys, time
 sys.path.insert(0, '.')
 import numpy as np
@@ -8,7 +8,7 @@ from unityraytracer_amd import Context, RayTraceMaster, scenes
 ctx = Context(0)
 for name in (sys.argv[1:] or ["C4", "C5"]):
     sc = scenes.CONFIGS[name](640, 360)
-    for builder in (0, 1):
+    for builder in (0, 1, 2, 3):
         ctx.set_option("blas_builder", builder)
         m = RayTraceMaster(ctx, sc)
         m.OnRenderImage(); first = ctx.scene_info()["prepare_ms"]
@@ -36,7 +36,7 @@ for name in (sys.argv[1:] or ["C4", "C5"]):
         for k in range(len(allm)):
             mat = np.asarray(allm[k]["localToWorldMatrix"], np.float32).copy(); mat[12] += 0.05 * (k + 1); allm[k]["localToWorldMatrix"] = mat
         t_all = reupload(allm)
-        print(f"{name} {sc.n_triangles} triangles, {len(sc.mesh_objects)} MeshObjects, builder {'GPU LBVH' if builder else 'host SAH'}: first {first:.1f} ms; "
+        print(f"{name} {sc.n_triangles} triangles, {len(sc.mesh_objects)} MeshObjects, builder {('host SAH', 'GPU Karras tree', 'GPU depth-budgeted tree', 'GPU binned SAH')[builder]}: first {first:.1f} ms; "
               f"re-upload unchanged: not stale ({tag[0]}); one moved {t_one:.2f} ms [{tag[3]}]" + (f" ({b1 - b0} built, {r1 - r0} reused)" if not builder else "") + f"; all moved {t_all:.2f} ms [{tag[4]}]", flush=True)
         m.OnDisable()
 ctx.set_option("blas_builder", 0)
