@@ -154,3 +154,57 @@ def test_c5_scene_preparation_under_10_ms(gpu_ctx, builder, limit_ms):
     m.OnDisable()
     print(f"C5 host SAH scene preparation: {host_ms:.1f} ms")
     assert bits_equal(img, ref)
+
+
+def degenerate_scene():
+    """Meshes that give a splitter nothing to split on: 300 copies of ONE triangle (every centroid the same point), 257 triangles in
+    a row along x with identical y / z extents (two axes without extent), a fan of 64 triangles sharing one centroid line, next to an
+    ordinary blob — the builders must terminate, stay inside their level buffers and give the pixels of the host tree."""
+    b = scenes.MeshSceneBuilder()
+    mat = scenes._params((0.7, 0.6, 0.5), (0.1, 0.1, 0.1), (0, 0, 0), 0.4)
+    tri = np.array([[-0.5, 0.2, 0.0], [0.5, 0.2, 0.0], [0.0, 1.2, 0.0]], np.float32)
+    b.add(tri, np.tile(np.array([0, 1, 2], np.int32), 300), scenes.trs(translate=(-2.5, 0.3, 0.0)), mat)
+    vs, ts = [], []
+    for k in range(257):
+        x = 0.02 * k
+        vs += [[x, 0.2, 0.0], [x + 0.015, 0.2, 0.0], [x + 0.0075, 1.0, 0.0]]
+        ts += [3 * k, 3 * k + 1, 3 * k + 2]
+    b.add(np.array(vs, np.float32), np.array(ts, np.int32), scenes.trs(translate=(-1.0, 0.1, 1.0)), mat)
+    vs, ts = [[0.0, 1.0, 0.0]], []
+    for k in range(65):
+        a = 2 * np.pi * k / 64
+        vs.append([np.cos(a), 1.0 + 0.3 * np.sin(3 * a), np.sin(a)])
+    for k in range(64):
+        ts += [0, k + 2, k + 1]
+    b.add(np.array(vs, np.float32), np.array(ts, np.int32), scenes.trs(translate=(2.5, 0.0, 0.5), scale=(0.8, 0.8, 0.8)), mat)
+    v, t = scenes.uv_blob(24, 17)
+    b.add(v, t, scenes.trs(translate=(0.5, 1.0, 2.5)), mat)
+    mo, vv, ii, nn, bvh = b.finish()
+    sc = scenes.Scene("degenerate", 144, 88, 4, 1, mesh_objects=mo, vertices=vv, indices=ii, normals=nn, mesh_bvh=bvh,
+                      spheres=np.zeros(0, scenes.SPHERE_DT), sphere_bvh=np.zeros(0, scenes.BVHNODE_DT), sky=scenes.make_sky(64, 32))
+    return sc.resized(144, 88, position=(0.0, 1.5, -7.0), fov_deg=70.0)
+
+
+def test_degenerate_meshes_through_every_builder(gpu_ctx):
+    sc = degenerate_scene()
+    gpu_ctx.set_option("kernel_mode", 3)
+    ref = None
+    try:
+        for builder in (0, 1, 2, 3):
+            gpu_ctx.set_option("blas_builder", builder)
+            m, img, _ = render(gpu_ctx, sc, frames=2)
+            nodes, tri, root, info = gpu_ctx.read_scene_blas(len(sc.mesh_objects))
+            assert gpu_ctx.counters()["watchdog_trips"] == 0
+            m.OnDisable()
+            assert len(tri) == sc.n_triangles and sorted(tri.tolist()) == sorted(set(tri.tolist())), builder      # every index slot exactly once
+            assert validate(sc, nodes, tri, root) <= info["max_depth"] <= 40, (builder, info)
+            if ref is None:
+                ref = img
+            assert bits_equal(img, ref), builder
+    finally:
+        gpu_ctx.set_option("blas_builder", 0)
+    o = pyoracle.Oracle(sc)
+    o.build_own_blas()
+    ox, oy, sd = scenes.frame_uniforms(1)
+    o.set_frame((ox, oy), sd)
+    assert bits_equal(ref, o.render(mode=1, threads=8))
