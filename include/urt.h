@@ -98,6 +98,15 @@ URT_API int urt_texture_create_external(urt_context* ctx, int width, int height,
  * in for presenting _converged, RM:819.)  Both synchronise. */
 URT_API int urt_texture_set_pixels(urt_context* ctx, urt_handle texture, const float* rgba);
 URT_API int urt_texture_get_pixels(urt_context* ctx, urt_handle texture, float* rgba);
+/* Pipelined readback for a host that LOOKS at every frame on the CPU (the reference presents on the GPU, RM:819; a host on another
+ * device — or Unity's own `destination` behind the shim — needs the pixels in host memory).  urt_texture_get_pixels waits for the frame
+ * and then for 33 MB over PCIe into pageable memory (2.2 ms at 1080p) before the next frame can start.  begin: submits the deferred
+ * work, snapshots the image AS IT IS AT THIS POINT of the program order (a device copy on the render stream) and sends the snapshot to a
+ * pinned host image on a copy stream of the library's own — it returns at once and later frames render while the snapshot travels;
+ * end: waits for that one copy and hands out the pinned image (width x height x 4 floats, row 0 = bottom), valid until the third
+ * urt_texture_read_begin after the one that made the ticket.  Up to three readbacks may be in flight.  A watchdog trip is reported by end. */
+URT_API int urt_texture_read_begin(urt_context* ctx, urt_handle texture, uint64_t* out_ticket);
+URT_API int urt_texture_read_end(urt_context* ctx, uint64_t ticket, const float** out_rgba);
 URT_API int urt_texture_get_info(urt_context* ctx, urt_handle texture, int* out_width, int* out_height,
                                  void** out_device_ptr);
 /* texture.Release()                                                  RM:830-831 */

@@ -51,6 +51,8 @@ internal static class UrtNative {
     [DllImport(Lib)] internal static extern int urt_texture_pack_rows(IntPtr ctx, ulong texture, int firstGroupRow, int rowStride, IntPtr deviceDst, out ulong bytes);
     [DllImport(Lib)] internal static extern int urt_texture_unpack_rows(IntPtr ctx, ulong texture, int firstGroupRow, int rowStride, IntPtr deviceSrc);
     [DllImport(Lib)] internal static extern int urt_texture_unpack_rows_on(IntPtr ctx, ulong texture, int firstGroupRow, int rowStride, IntPtr deviceSrc, IntPtr hipStream);
+    [DllImport(Lib)] internal static extern int urt_texture_read_begin(IntPtr ctx, ulong texture, out ulong ticket);
+    [DllImport(Lib)] internal static extern int urt_texture_read_end(IntPtr ctx, ulong ticket, out IntPtr rgba);   // pinned host image, width x height x 4 floats
     [DllImport(Lib)] internal static extern int urt_texture_pack_rows_rgb(IntPtr ctx, ulong texture, int firstGroupRow, int rowStride, IntPtr deviceDst, out ulong bytes);
     [DllImport(Lib)] internal static extern int urt_texture_unpack_rows_rgb(IntPtr ctx, ulong texture, int firstGroupRow, int rowStride, IntPtr deviceSrc, float alpha, IntPtr hipStream);
 

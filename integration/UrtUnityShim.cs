@@ -128,6 +128,23 @@ public static class UrtGraphics {
         UrtDevice.Check(UrtDevice.IsGroup ? UrtNative.urt_group_gather(UrtDevice.Handle, src.handle, dst.handle)
                                           : UrtNative.urt_blit(UrtDevice.Handle, src.handle, dst.handle));
     }
+    /// Present through Unity WITHOUT stalling the tracer: the frame that is presented is the previous call's (one frame of latency).
+    /// urt_texture_read_begin snapshots `src` and sends it to a pinned host image on a copy stream while the next frames render;
+    /// urt_texture_read_end hands that image out, and Texture2D.LoadRawTextureData takes it without a managed copy.
+    static ulong pendingTicket = 0;
+    public static void BlitPipelined(UrtRenderTexture src, RenderTexture unityDestination, ref Texture2D staging) {
+        if (UrtDevice.IsGroup) throw new NotSupportedException("pipelined readback is per device: gather to rank 0's image first");
+        if (staging == null || staging.width != src.width || staging.height != src.height)
+            staging = new Texture2D(src.width, src.height, TextureFormat.RGBAFloat, false, true);
+        if (pendingTicket != 0) {
+            IntPtr rgba;
+            UrtDevice.Check(UrtNative.urt_texture_read_end(UrtDevice.Handle, pendingTicket, out rgba));
+            staging.LoadRawTextureData(rgba, src.width * src.height * 16);
+            staging.Apply(false);
+            Graphics.Blit(staging, unityDestination);
+        }
+        UrtDevice.Check(UrtNative.urt_texture_read_begin(UrtDevice.Handle, src.handle, out pendingTicket));
+    }
     /// Present through Unity: read the image back (this submits and waits) and hand it to a Unity RenderTexture.
     public static void Blit(UrtRenderTexture src, RenderTexture unityDestination, ref Texture2D staging, ref float[] managed) {
         int n = src.width * src.height * 4;

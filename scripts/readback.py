@@ -16,4 +16,16 @@ for _ in range(n):
     m.OnRenderImage(); img = m._converged.GetPixels()
 t_rb = (time.perf_counter() - t) / n
 ctx.reset_counters(); m.OnRenderImage(); ctx.synchronize(); rays = ctx.counters()["rays"]
-print(f"frame without readback {t_trace*1e3:.3f} ms ({rays/t_trace/1e6:.0f} Mrays/s); with a full-frame readback every frame {t_rb*1e3:.3f} ms ({rays/t_rb/1e6:.0f} Mrays/s); readback alone {1e3*(t_rb-t_trace):.3f} ms for {img.nbytes/1e6:.1f} MB")
+# pipelined: frame i is read while frames i+1, i+2 render (urt_texture_read_begin / _end, two in flight)
+tickets = []
+t = time.perf_counter()
+for _ in range(n):
+    m.OnRenderImage()
+    tickets.append(m._converged.ReadBegin())
+    if len(tickets) > 2:
+        img2 = m._converged.ReadEnd(tickets.pop(0), copy=False)
+while tickets:
+    img2 = m._converged.ReadEnd(tickets.pop(0), copy=False)
+t_pipe = (time.perf_counter() - t) / n
+print(f"frame without readback {t_trace*1e3:.3f} ms ({rays/t_trace/1e6:.0f} Mrays/s); with a full-frame readback every frame {t_rb*1e3:.3f} ms ({rays/t_rb/1e6:.0f} Mrays/s); readback alone {1e3*(t_rb-t_trace):.3f} ms for {img.nbytes/1e6:.1f} MB; "
+      f"PIPELINED readback of every frame (urt_texture_read_begin / _end, two frames in flight, the pinned image handed out) {t_pipe*1e3:.3f} ms per frame ({rays/t_pipe/1e6:.0f} Mrays/s)")

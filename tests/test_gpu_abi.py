@@ -261,3 +261,40 @@ def test_launch_info_names_the_kernel_that_ran(gpu_ctx):
         gpu_ctx.set_option("count_stats", 0)
         gpu_ctx.set_option("kernel_mode", 3)
         m.OnDisable()
+
+
+def test_pipelined_readback_sees_the_frame_it_was_asked_for(gpu_ctx):
+    """urt_texture_read_begin / _end: every ticket delivers the image as it was when ITS begin was called, while later frames — deferred
+    and batched or not — render; three may be in flight, a fourth is refused, an ended ticket cannot be ended twice."""
+    import ctypes as C
+    from unityraytracer_amd import RayTraceMaster, UrtError, scenes
+    sc = scenes.mixed_test_scene(168, 96)
+    for fpl in (1, 0):
+        gpu_ctx.set_option("kernel_mode", 3)
+        gpu_ctx.set_option("frames_per_launch", fpl)
+        try:
+            m = RayTraceMaster(gpu_ctx, sc)
+            want = []
+            for _ in range(7):
+                m.OnRenderImage()
+                want.append(m._converged.GetPixels())
+            m.OnDisable()
+            m = RayTraceMaster(gpu_ctx, sc)
+            tickets, got = [], []
+            for i in range(7):
+                m.OnRenderImage()
+                tickets.append(m._converged.ReadBegin())
+                if len(tickets) == 3:
+                    with pytest.raises(UrtError):
+                        m._converged.ReadBegin()              # three in flight: the oldest must be ended first
+                    got.append(m._converged.ReadEnd(tickets.pop(0)))
+            while tickets:
+                got.append(m._converged.ReadEnd(tickets.pop(0)))
+            with pytest.raises(UrtError):
+                m._converged.ReadEnd(1)                        # long ended
+            m.OnDisable()
+            assert len(got) == 7
+            for i in range(7):
+                assert np.array_equal(got[i].view(np.uint32), want[i].view(np.uint32)), (fpl, i)
+        finally:
+            gpu_ctx.set_option("frames_per_launch", 0)

@@ -18,7 +18,7 @@ ERROR_NAMES = {1: "INVALID_ARGUMENT", 2: "INVALID_HANDLE", 3: "NO_DEVICE", 4: "H
 ABI_SYMBOLS = [
     "urt_abi_version", "urt_device_count", "urt_context_create", "urt_context_destroy", "urt_last_error", "urt_context_set_stream",
     "urt_synchronize", "urt_flush", "urt_buffer_create", "urt_buffer_set_data", "urt_buffer_get_info", "urt_buffer_release", "urt_texture_create",
-    "urt_texture_create_external", "urt_texture_set_pixels", "urt_texture_get_pixels", "urt_texture_get_info", "urt_texture_release",
+    "urt_texture_create_external", "urt_texture_set_pixels", "urt_texture_get_pixels", "urt_texture_get_info", "urt_texture_read_begin", "urt_texture_read_end", "urt_texture_release",
     "urt_shader_set_buffer", "urt_shader_set_texture", "urt_shader_set_matrix", "urt_shader_set_vector", "urt_shader_set_float",
     "urt_shader_set_int", "urt_shader_dispatch", "urt_shader_dispatch_rows", "urt_blit_add", "urt_blit", "urt_texture_pack_rows",
     "urt_texture_unpack_rows", "urt_texture_unpack_rows_on", "urt_texture_pack_rows_rgb", "urt_texture_unpack_rows_rgb", "urt_set_option", "urt_get_counters", "urt_reset_counters", "urt_debug_build_blas", "urt_debug_get_blas", "urt_debug_blas_cache_stats",
@@ -100,6 +100,8 @@ def load():
         "urt_texture_set_pixels": ([vp, u64, vp], i),
         "urt_texture_get_pixels": ([vp, u64, vp], i),
         "urt_texture_get_info": ([vp, u64, pi, pi, C.POINTER(vp)], i),
+        "urt_texture_read_begin": ([vp, u64, C.POINTER(u64)], i),
+        "urt_texture_read_end": ([vp, u64, C.POINTER(C.POINTER(C.c_float))], i),
         "urt_texture_release": ([vp, u64], i),
         "urt_shader_set_buffer": ([vp, i, C.c_char_p, u64], i),
         "urt_shader_set_texture": ([vp, i, C.c_char_p, u64], i),

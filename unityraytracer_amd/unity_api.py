@@ -230,6 +230,20 @@ class RenderTexture:
         self.ctx.check(self.ctx.lib.urt_texture_get_pixels(self.ctx._h, self.handle, out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def ReadBegin(self) -> int:
+        """Start a pipelined readback of the image as it is now (include/urt.h urt_texture_read_begin); returns a ticket."""
+        t = C.c_uint64()
+        self.ctx.check(self.ctx.lib.urt_texture_read_begin(self.ctx._h, self.handle, C.byref(t)))
+        return t.value
+
+    def ReadEnd(self, ticket: int, copy: bool = True) -> np.ndarray:
+        """Wait for that readback; the image as (height, width, 4) float32 — a copy, or (copy=False) a view of the library's pinned
+        buffer that stays valid until the third ReadBegin after the ticket's."""
+        p = C.POINTER(C.c_float)()
+        self.ctx.check(self.ctx.lib.urt_texture_read_end(self.ctx._h, C.c_uint64(ticket), C.byref(p)))
+        a = np.ctypeslib.as_array(p, shape=(self.height, self.width, 4))
+        return a.copy() if copy else a
+
     def device_ptr(self) -> int:
         p = C.c_void_p()
         self.ctx.check(self.ctx.lib.urt_texture_get_info(self.ctx._h, self.handle, None, None, C.byref(p)))
