@@ -208,3 +208,29 @@ def test_degenerate_meshes_through_every_builder(gpu_ctx):
     ox, oy, sd = scenes.frame_uniforms(1)
     o.set_frame((ox, oy), sd)
     assert bits_equal(ref, o.render(mode=1, threads=8))
+
+
+@pytest.mark.parametrize("leaf_max", [1, 4])
+def test_gpu_builders_with_other_leaf_sizes_and_a_chain_shaped_mesh(gpu_ctx, leaf_max):
+    """blas_leaf_max 1 (the most nodes and bin words a level of the GPU SAH builder can need) and 4, and the chain-shaped mesh whose SAH
+    tree is as deep as it is long: every GPU builder gives a valid tree and the pixels of the host tree."""
+    gpu_ctx.set_option("kernel_mode", 3)
+    try:
+        gpu_ctx.set_option("blas_leaf_max", leaf_max)
+        for sc in (scenes.mixed_test_scene(120, 72, blob=(30, 23)), scenes.deep_chain_scene(96, 64, n=40)):
+            ref = None
+            for builder in (0, 1, 2, 3):
+                gpu_ctx.set_option("blas_builder", builder)
+                m, img, _ = render(gpu_ctx, sc)
+                nodes, tri, root, info = gpu_ctx.read_scene_blas(len(sc.mesh_objects))
+                m.OnDisable()
+                assert sorted(tri.tolist()) == list(range(0, 3 * sc.n_triangles, 3)), (sc.name, builder)
+                assert validate(sc, nodes, tri, root) <= info["max_depth"], (sc.name, builder, info)
+                leaves = nodes[:, 12:14].view(np.int32)
+                assert int((((~leaves[leaves < 0]) & 7) + 1).max()) <= max(leaf_max, 1) or builder == 0
+                if ref is None:
+                    ref = img
+                assert bits_equal(img, ref), (sc.name, builder)
+    finally:
+        gpu_ctx.set_option("blas_builder", 0)
+        gpu_ctx.set_option("blas_leaf_max", 2)

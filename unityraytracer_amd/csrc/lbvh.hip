@@ -535,7 +535,7 @@ __device__ __forceinline__ float sbox_half_area(const SBox& b) {
 
 // one thread per node of the level: the sweep of blas_builder.cpp (right-to-left suffix areas, left-to-right costs, first strict minimum over
 // axes 0, 1, 2), the sizes of the two sides, how many of them need a node of their own, and the bin words those will take
-__global__ __launch_bounds__(64) void k_sah_eval(Dev D, int src, int n_nodes) {
+__global__ __launch_bounds__(64) void k_sah_eval(Dev D, int src, int n_nodes, int level) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_nodes) return;
   int4 rg = D.sl_rng[src][i];
@@ -561,7 +561,7 @@ __global__ __launch_bounds__(64) void k_sah_eval(Dev D, int src, int n_nodes) {
     }
   }
   int nl = best_nl;
-  if (best_axis < 0 || nl <= 0 || nl >= size) { best_axis = -1; nl = size / 2; }      // no plane separates: halve by the current order (keeps the tree finite)
+  if (best_axis < 0 || nl <= 0 || nl >= size || level > 56) { best_axis = -1; nl = size / 2; }      // no plane separates (or, as in blas_builder.cpp, the tree is 56 levels deep): halve by the current order — keeps the tree finite
   const int nr = size - nl;
   const int kids = (nl > D.leaf_max) + (nr > D.leaf_max);
   D.sl_dec[i] = make_int4(best_axis, best_bin, nl, kids);
@@ -589,7 +589,15 @@ __global__ __launch_bounds__(64) void k_sah_emit(Dev D, int src, int n_nodes, in
     const float clo[3] = {ord2f(b0.x), ord2f(b0.y), ord2f(b0.z)}, chi[3] = {ord2f(b0.w), ord2f(b1.x), ord2f(b1.y)};
     bool any = false;
     for (int ax = 0; ax < 3 && !any; ax++) if (chi[ax] - clo[ax] > 0.0f) { const unsigned int* A = B + ax * nb * 7; for (int b = 0; b < nb; b++) if (A[b * 7]) sbox_grow(bl, A + b * 7); any = true; }
-    if (!any) { float e = __uint_as_float(D.stats[m].ext); for (int k = 0; k < 3; k++) { bl.lo[k] = -e; bl.hi[k] = e; } }   // all centroids coincide: the MeshObject's extent
+    if (!any) {
+      // all centroids coincide, nothing was binned: the box the PARENT recorded for this child (its pad taken off again), or for a root the MeshObject's extent
+      if (rg.z >= 0) {
+        const float4* pn = D.nodes + 4 * (size_t)rg.z;
+        float4 q0 = pn[0], q1 = pn[1], q2 = pn[2];
+        if ((rg.w & 1) == 0) { bl.lo[0] = q0.x + pad; bl.lo[1] = q0.y + pad; bl.lo[2] = q0.z + pad; bl.hi[0] = q0.w - pad; bl.hi[1] = q1.x - pad; bl.hi[2] = q1.y - pad; }
+        else { bl.lo[0] = q1.z + pad; bl.lo[1] = q1.w + pad; bl.lo[2] = q2.x + pad; bl.hi[0] = q2.y - pad; bl.hi[1] = q2.z - pad; bl.hi[2] = q2.w - pad; }
+      } else { float e = __uint_as_float(D.stats[m].ext); for (int k = 0; k < 3; k++) { bl.lo[k] = -e; bl.hi[k] = e; } }
+    }
     br = bl;
   }
   const int id = level_base + i;
@@ -773,7 +781,8 @@ int lbvh_build(const LbvhInput& in, hipStream_t st, LbvhOutput& out, std::string
   const size_t LN = in.sah ? (size_t)T / 2 + (size_t)nm + 2 : 0;          // most nodes a level can have (every node has > leaf_max >= 1 triangles)
   size_t o_sidx[2] = {0, 0}, o_snode[2] = {0, 0}, o_sflag = 0, o_sscan = 0, o_slrng[2] = {0, 0}, o_slcb0[2] = {0, 0}, o_slcb1[2] = {0, 0}, o_slbo[2] = {0, 0};
   size_t o_sldec = 0, o_slcnt = 0, o_slcscan = 0, o_slwords = 0, o_slwscan = 0, o_sbins = 0;
-  const size_t bin_words = in.sah ? 72 * (size_t)T + 4096 : 0;
+  // bin words a level can need: nodes of fewer than 64 triangles take 3 x 8 x 7 = 168 words and have > leaf_max triangles, bigger ones 672 per >= 64
+  const size_t bin_words = in.sah ? (168 / ((size_t)std::min(std::max(in.leaf_max, 1), 8) + 1) + 12) * (size_t)T + 4096 : 0;
   if (in.sah) {
     for (int k = 0; k < 2; k++) {
       o_sidx[k] = carve(4 * (size_t)T); o_snode[k] = carve(4 * (size_t)T);
@@ -849,7 +858,7 @@ int lbvh_build(const LbvhInput& in, hipStream_t st, LbvhOutput& out, std::string
       if (n > LN || words > bin_words || sah_levels >= 120) { err = "GPU SAH builder: level " + std::to_string(sah_levels) + " does not fit its buffers"; if (temp) (void)hipFree(temp); for (void* q : out.allocs) (void)hipFree(q); out = LbvhOutput(); return URT_ERR_SCENE; }
       hipLaunchKernelGGL(k_sah_bins_init, blocks(words, 256), dim3(256), 0, st, D, (int)words);
       hipLaunchKernelGGL(k_sah_bin, dim3(gb), dim3(256), 0, st, D, src);
-      hipLaunchKernelGGL(k_sah_eval, blocks(n, 64), dim3(64), 0, st, D, src, (int)n);
+      hipLaunchKernelGGL(k_sah_eval, blocks(n, 64), dim3(64), 0, st, D, src, (int)n, sah_levels);
       LBVH_HIP(scan(D.sl_cnt, D.sl_cscan, n));
       LBVH_HIP(scan(D.sl_words, D.sl_wscan, n));
       hipLaunchKernelGGL(k_sah_emit, blocks(n, 64), dim3(64), 0, st, D, src, (int)n, level_base);
