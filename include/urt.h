@@ -185,7 +185,8 @@ typedef struct urt_counters {
                               there is a bug; when not, the next urt_synchronize / urt_texture_get_pixels fails with URT_ERR_WATCHDOG */
   uint64_t launches;      /* trace-kernel launches those dispatches became (< dispatches when frames were batched) */
 } urt_counters;
-/* Options: "blas_builder" (0 = binned-SAH triangle BVH built on host threads, the default: best trees; 1 = LBVH built on the GPU
+/* Options: "blas_builder" (-1 = auto, the default: 0 for scenes of fewer than 200,000 triangles, 3 from there on;
+ *                          0 = binned-SAH triangle BVH built on host threads: best trees; 1 = LBVH built on the GPU
  *                          from the uploaded buffers — Morton sort + Karras hierarchy, csrc/lbvh.hip: milliseconds instead of tens
  *                          of milliseconds for scenes whose objects move; 2 = the same radix tree built top-down within a depth
  *                          budget ("lbvh_slack", default 6 levels beyond a median tree): the traversal stacks live in LDS and a
@@ -369,6 +370,7 @@ typedef struct urt_launch_info {
   int lds_tables;             /* bit 0 mesh heap, 1 sphere heap + spheres, 2 single-leaf triangle records, 3 walk table */
   int slab_frames, slab_frames_max, slab_out_of_memory;
   int experiment;             /* 1: the library is an A/B / probe / diagnostic build (negative urt_abi_version) */
+  int blas_builder;           /* the triangle-BVH builder the scene's last full preparation used (0..3; what "blas_builder" -1 = auto resolved to) */
 } urt_launch_info;
 URT_API int urt_debug_launch_info(urt_context* ctx, urt_launch_info* out_info);
 URT_API int urt_debug_read_scene_blas(urt_context* ctx, float* nodes, int32_t* tri_index, int32_t* mesh_root);

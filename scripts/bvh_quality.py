@@ -46,4 +46,4 @@ for cfg in sys.argv[1:] or ["C3", "C3D", "C4", "C5"]:
             cost_i += 1.0 + ci / ra; cost_l += cl / ra
         print(f"{cfg:4s} builder {builder}: nodes {info['n_nodes']:7d} depth {info['max_depth']:3d}  SA cost interior {cost_i:8.2f} leaves {cost_l:8.2f}  |  per ray: "
               f"BVH nodes {c['blas_nodes'] / c['rays']:6.2f} triangle tests {c['tri_tests'] / c['rays']:5.2f}  prepare {info['prepare_ms']:.1f} ms", flush=True)
-ctx.set_option("blas_builder", 0)
+ctx.set_option("blas_builder", -1)

@@ -39,4 +39,4 @@ for name in (sys.argv[1:] or ["C4", "C5"]):
         print(f"{name} {sc.n_triangles} triangles, {len(sc.mesh_objects)} MeshObjects, builder {('host SAH', 'GPU Karras tree', 'GPU depth-budgeted tree', 'GPU binned SAH')[builder]}: first {first:.1f} ms; "
               f"re-upload unchanged: not stale ({tag[0]}); one moved {t_one:.2f} ms [{tag[3]}]" + (f" ({b1 - b0} built, {r1 - r0} reused)" if not builder else "") + f"; all moved {t_all:.2f} ms [{tag[4]}]", flush=True)
         m.OnDisable()
-ctx.set_option("blas_builder", 0)
+ctx.set_option("blas_builder", -1)

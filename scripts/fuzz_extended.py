@@ -46,7 +46,7 @@ for k in range(count):
         print(f"seed {seed} mode {mode} builder {builder}: {bad} pixels differ, watchdog {wd} ({len(sc.spheres)} spheres, {len(sc.mesh_objects)} meshes, {sc.n_triangles} triangles)", flush=True)
     if (k + 1) % 25 == 0:
         print(f"{k + 1} scenes, {bad_total} failing, {time.time() - t0:.0f} s", flush=True)
-ctx.set_option("blas_builder", 0); ctx.set_option("kernel_mode", 3)
+ctx.set_option("blas_builder", -1); ctx.set_option("kernel_mode", 3)
 print(f"done: {count} scenes from seed {first}, {bad_total} failing; {pixels} pixel-frames compared bit for bit, {with_mesh} scenes with MeshObjects ({tris} triangles in all), "
       f"mean image level {lum / count:.3f}, {time.time() - t0:.1f} s")
 sys.exit(1 if bad_total else 0)

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from oracle import pyoracle
-from unityraytracer_amd import RayTraceMaster, debug_build_blas, scenes
+from unityraytracer_amd import RayTraceMaster, scenes
 
 pytestmark = pytest.mark.gpu
 
@@ -28,11 +28,6 @@ def threads():
 @pytest.mark.parametrize("cfg", ["C2", "C3", "C4", "C5"])
 def test_full_size_config_bit_exact(gpu_ctx, cfg):
     sc = scenes.CONFIGS[cfg]()
-    o = pyoracle.Oracle(sc)
-    if len(sc.mesh_objects):
-        nodes, tri, root, _, _ = debug_build_blas(sc.mesh_objects, sc.vertices, sc.indices)
-        o.set_blas(nodes, tri, root)
-    ref, oc = o.render(mode=1, threads=threads(), counters=True)
     gpu_ctx.set_option("kernel_mode", 3)
     gpu_ctx.set_option("count_stats", 1)
     gpu_ctx.reset_counters()
@@ -41,6 +36,14 @@ def test_full_size_config_bit_exact(gpu_ctx, cfg):
     img = m._target.GetPixels()
     gc = gpu_ctx.counters()
     gpu_ctx.set_option("count_stats", 0)
+    # the oracle walks the tree the product REALLY used (default builder: the host's SAH below 200,000 triangles, the GPU's from there on —
+    # C4 and C5), read back from the device, so that the traversal counters can be compared event for event whichever builder ran
+    o = pyoracle.Oracle(sc)
+    if len(sc.mesh_objects):
+        nodes, tri, root, _ = gpu_ctx.read_scene_blas(len(sc.mesh_objects))
+        o.set_blas(nodes, tri, root)
+        assert gpu_ctx.launch_info()["blas_builder"] == (3 if sc.n_triangles >= 200000 else 0), gpu_ctx.launch_info()
+    ref, oc = o.render(mode=1, threads=threads(), counters=True)
     same = np.array_equal(img.view(np.uint32), ref.view(np.uint32))
     if not same:
         d = np.abs(img.astype(np.float64) - ref.astype(np.float64))

@@ -67,7 +67,7 @@ def test_random_scene_bit_exact(gpu_ctx, seed):
         got_t, got_c = m._target.GetPixels(), m._converged.GetPixels()
         m.OnDisable()
     finally:
-        gpu_ctx.set_option("blas_builder", 0)
+        gpu_ctx.set_option("blas_builder", -1)
     o = pyoracle.Oracle(sc)
     if len(sc.mesh_objects):
         o.build_own_blas()

@@ -22,7 +22,7 @@ def lbvh(gpu_ctx, request):
     gpu_ctx.set_option("kernel_mode", 3)
     gpu_ctx.set_option("blas_builder", request.param)
     yield gpu_ctx
-    gpu_ctx.set_option("blas_builder", 0)
+    gpu_ctx.set_option("blas_builder", -1)
 
 
 def render(ctx, sc, frames=1):
@@ -79,7 +79,7 @@ def test_frames_equal_host_built_tree_and_oracle(gpu_ctx, scene_fn, builder):
             assert bits_equal(t2, t0), mode
     finally:
         gpu_ctx.set_option("kernel_mode", 3)
-        gpu_ctx.set_option("blas_builder", 0)
+        gpu_ctx.set_option("blas_builder", -1)
     assert bits_equal(t1, t0) and bits_equal(c1, c0)
     o = pyoracle.Oracle(sc)
     o.build_own_blas()
@@ -144,16 +144,25 @@ def test_c5_scene_preparation_under_10_ms(gpu_ctx, builder, limit_ms):
         img = m._target.GetPixels()
         m.OnDisable()
     finally:
-        gpu_ctx.set_option("blas_builder", 0)
+        gpu_ctx.set_option("blas_builder", -1)
     print(f"C5 GPU scene preparation (builder {builder}): {times} ms, {info}")
     assert info["n_tris"] == 983040 and min(times) <= limit_ms, times
-    m = RayTraceMaster(gpu_ctx, sc)                              # host SAH tree: same pixels
-    m.OnRenderImage()
-    ref = m._target.GetPixels()
-    host_ms = gpu_ctx.scene_info()["prepare_ms"]
-    m.OnDisable()
+    gpu_ctx.set_option("blas_builder", 0)                        # host SAH tree: same pixels
+    try:
+        m = RayTraceMaster(gpu_ctx, sc)
+        m.OnRenderImage()
+        ref = m._target.GetPixels()
+        host_ms = gpu_ctx.scene_info()["prepare_ms"]
+        assert gpu_ctx.launch_info()["blas_builder"] == 0
+        m.OnDisable()
+    finally:
+        gpu_ctx.set_option("blas_builder", -1)
     print(f"C5 host SAH scene preparation: {host_ms:.1f} ms")
     assert bits_equal(img, ref)
+    m = RayTraceMaster(gpu_ctx, sc)                              # the default (auto) picks the GPU's SAH builder for a scene of this size
+    m.OnRenderImage()
+    assert gpu_ctx.launch_info()["blas_builder"] == 3 and bits_equal(m._target.GetPixels(), ref)
+    m.OnDisable()
 
 
 def degenerate_scene():
@@ -202,7 +211,7 @@ def test_degenerate_meshes_through_every_builder(gpu_ctx):
                 ref = img
             assert bits_equal(img, ref), builder
     finally:
-        gpu_ctx.set_option("blas_builder", 0)
+        gpu_ctx.set_option("blas_builder", -1)
     o = pyoracle.Oracle(sc)
     o.build_own_blas()
     ox, oy, sd = scenes.frame_uniforms(1)
@@ -232,5 +241,5 @@ def test_gpu_builders_with_other_leaf_sizes_and_a_chain_shaped_mesh(gpu_ctx, lea
                     ref = img
                 assert bits_equal(img, ref), (sc.name, builder)
     finally:
-        gpu_ctx.set_option("blas_builder", 0)
+        gpu_ctx.set_option("blas_builder", -1)
         gpu_ctx.set_option("blas_leaf_max", 2)

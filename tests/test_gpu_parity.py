@@ -172,7 +172,7 @@ def test_masked_phase_at_fewer_workgroups_per_cu(gpu_ctx):
         assert_same(gpu, ref, "C4 small, GPU-built tree")
         assert gc["watchdog_trips"] == 0
     finally:
-        gpu_ctx.set_option("stack_pad", 0); gpu_ctx.set_option("blas_builder", 0)
+        gpu_ctx.set_option("stack_pad", 0); gpu_ctx.set_option("blas_builder", -1)
 
 
 def test_chain_shaped_triangle_bvh_fills_the_traversal_stack(gpu_ctx):

@@ -116,7 +116,7 @@ def test_moved_meshes_are_refitted_not_rebuilt(gpu_ctx, other_ctx, builder):
         assert bits_equal(m._target.GetPixels(), o.render(mode=1, threads=8))
         m.OnDisable()
     finally:
-        gpu_ctx.set_option("blas_builder", 0)
+        gpu_ctx.set_option("blas_builder", -1)
 
 
 def test_refit_inside_deferred_frames_and_c5_cost(gpu_ctx, other_ctx):

@@ -162,7 +162,8 @@ struct urt_context {
   // per dispatch), the AdditionShader blits that follow the dispatches are deferred with them and run in order after the
   // launch.  Everything else that could observe the images flushes first, so the in-order semantics of RM:806-820
   // stay exactly observable.
-  int opt_blas_builder = 0;                 // 0 = binned SAH on host threads (best trees), 1 = LBVH built on the GPU (dynamic scenes), 2 = the same tree built top-down within a depth budget (csrc/lbvh.hip k_td_level)
+  int opt_blas_builder = -1;                // -1 = auto (default): 0 below kGpuBuildTriangles triangles, 3 from there on; 0 = binned SAH on host threads, 1 = Karras radix tree built on the GPU,
+                                            // 2 = the same tree built top-down within a depth budget, 3 = binned SAH on the GPU (csrc/lbvh.hip): the host's trees at a fifth of the time on big scenes
   float last_prepare_ms = 0;                // host wall time of the last scene preparation (buffers -> device scene)
   int n_scene_tris = 0;                     // triangles of the prepared scene
   int walk_f4 = 0;                          // float4s of the masked-walk table behind the mesh heap's device copy (0 = none: heap > 31 nodes)
@@ -194,6 +195,7 @@ struct urt_context {
   int opt_watchdog_cap = 0;                 // test hook: scheduler trips per wave (0 = auto, scaled with the launch)
   int slab_frames_max = 0;                  // largest batch the Result slab could be allocated for (after out-of-memory retries)
   urt_launch_info last_launch{};            // the last trace launch of this context (urt_debug_launch_info)
+  int last_builder = 0;                     // the triangle-BVH builder the last full scene preparation used (0..3)
   // pipelined readback (urt_texture_read_begin / _end): kReadSlots snapshots in flight, each a device copy + a pinned host image
   static constexpr int kReadSlots = 3;
   struct ReadSlot { float4* dev = nullptr; float4* host = nullptr; size_t pixels = 0; hipEvent_t snap = nullptr, done = nullptr; bool busy = false; uint64_t ticket = 0; } rslot[kReadSlots];
@@ -629,7 +631,17 @@ int prepare_scene(urt_context* ctx) {
       pack_material(mo.lighting, mats.data() + (size_t)(n_spheres + m) * kMatFloats);
     }
     const float4* p;
-    if (ctx->opt_blas_builder >= 1) {
+    // auto: the host builder up to kGpuBuildTriangles triangles (C3's 69,600: 12 ms on the host, 6 on the GPU — and small scenes are what the
+    // per-MeshObject host cache is good at), the GPU's binned SAH beyond (C4 300 k: 32 -> 10 ms, C5 983 k: 80 -> 15 ms; same trees, same frames)
+    constexpr long kGpuBuildTriangles = 200000;
+    int builder = ctx->opt_blas_builder;
+    if (builder < 0) {
+      long tris = 0;
+      for (int m = 0; m < n_meshes; m++) { urt_MeshObject mo; std::memcpy(&mo, bm->host.data() + (size_t)m * URT_STRIDE_MESHOBJECT, sizeof mo); tris += std::max(0, mo.indices_count) / 3; }
+      builder = tris >= kGpuBuildTriangles ? 3 : 0;
+    }
+    ctx->last_builder = builder;
+    if (builder >= 1) {
       // device copies of the buffers exactly as SetData delivered them; the whole build runs on the GPU (csrc/lbvh.hip)
       std::vector<int32_t> offs((size_t)n_meshes), cnts((size_t)n_meshes);
       for (int m = 0; m < n_meshes; m++) {
@@ -653,7 +665,7 @@ int prepare_scene(urt_context* ctx) {
       in.vertices = bv ? (const float*)(rb + b_mo) : nullptr; in.n_vertices = bv ? bv->count : 0;
       in.indices = bi ? (const int32_t*)(rb + b_mo + b_v) : nullptr; in.n_indices = bi ? bi->count : 0;
       in.normals = bn ? (const float*)(rb + b_mo + b_v + b_i) : nullptr; in.n_normals = bn ? bn->count : 0;
-      in.h_offsets = offs.data(); in.h_counts = cnts.data(); in.leaf_max = get_blas_leaf_max(); in.depth_budget = ctx->opt_blas_builder == 2; in.depth_slack = ctx->opt_lbvh_slack; in.sah = ctx->opt_blas_builder == 3;
+      in.h_offsets = offs.data(); in.h_counts = cnts.data(); in.leaf_max = get_blas_leaf_max(); in.depth_budget = builder == 2; in.depth_slack = ctx->opt_lbvh_slack; in.sah = builder == 3;
       LbvhOutput o;
       std::string err;
       rc = lbvh_build(in, ctx->stream, o, err);
@@ -1817,7 +1829,7 @@ int urt_set_option(urt_context* ctx, const char* name, int value) {
   if (!name) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "option name is NULL");
   { (void)hipSetDevice(ctx->device); int rc = flush_pending(ctx); if (rc) return rc; }   // deferred frames run with the options they were dispatched under
   if (std::strcmp(name, "blas_builder") == 0) {
-    if (value < 0 || value > 3) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "blas_builder must be 0 (host SAH), 1 (GPU LBVH), 2 (GPU LBVH built top-down within a depth budget) or 3 (binned SAH on the GPU)");
+    if (value < -1 || value > 3) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "blas_builder must be -1 (auto), 0 (host SAH), 1 (GPU LBVH), 2 (GPU LBVH built top-down within a depth budget) or 3 (binned SAH on the GPU)");
     if (value != ctx->opt_blas_builder) { ctx->scene_dirty = true; ctx->dirty_full = true; }
     ctx->opt_blas_builder = value;
   } else if (std::strcmp(name, "frames_per_launch") == 0) {
@@ -2046,6 +2058,7 @@ int urt_debug_launch_info(urt_context* ctx, urt_launch_info* out) {
   int rc = flush_pending(ctx); if (rc) return rc;          // "the last launch" includes the frames still deferred
   *out = ctx->last_launch;
   out->slab_frames = ctx->slab_frames; out->slab_frames_max = ctx->slab_frames_max; out->slab_out_of_memory = ctx->slab_oom_stride != 0 ? 1 : 0;
+  out->blas_builder = ctx->last_builder;
   return URT_OK;
 }
 
