@@ -18,8 +18,14 @@
 //                     traversal); the rest keep Karras order, compacted by a prefix sum
 //   8. k_emit_nodes / k_emit_tris   64-byte two-child nodes with padded boxes, 48-byte triangle and normal records in
 //                     sorted (= leaf) order — the formats of urt_device.h, so the trace kernels do not know which builder ran.
+// Round 4 added two more builders on the same inputs and outputs ("blas_builder" 2 and 3; the default -1 = auto picks 3 for scenes of
+// 200,000 triangles or more, context.cpp prepare_scene):
+//   2  the radix tree built TOP-DOWN, one launch per level, with a depth budget (k_td_roots / k_td_level instead of k_karras): the
+//      traversal stacks live in LDS, and a 30-level Karras tree costs workgroups per CU;
+//   3  BINNED SAH, the host builder's algorithm level by level (k_sah_*): bins filled with LDS-privatised atomics, one thread per node
+//      sweeps them, a flag + scan + scatter pass partitions every range in place — the host's trees in a fifth of the time.
 // Any conservative BVH gives the same pixels: the closest-hit rule (strict t <, ties to the lower index slot, A.4) is in
-// the traversal, not in the tree.  tests/test_gpu_lbvh.py checks structure, bit-identical frames and the build time.
+// the traversal, not in the tree.  tests/test_gpu_lbvh.py checks structure, bit-identical frames and the build time of all three.
 #include <hip/hip_runtime.h>
 #include <string.h>                      // rocprim's texture_cache_iterator.hpp calls memset unqualified
 #include <cstring>
