@@ -107,6 +107,19 @@ URT_API int urt_texture_get_pixels(urt_context* ctx, urt_handle texture, float* 
  * urt_texture_read_begin after the one that made the ticket.  Up to three readbacks may be in flight.  A watchdog trip is reported by end. */
 URT_API int urt_texture_read_begin(urt_context* ctx, urt_handle texture, uint64_t* out_ticket);
 URT_API int urt_texture_read_end(urt_context* ctx, uint64_t ticket, const float** out_rgba);
+/* The same readback in the FORMAT of the host's `destination` (RM:819 blits _converged into whatever the camera renders to): the image
+ * is converted on the GPU (csrc/present.hip) and only the converted pixels cross the bus — 8.3 MB (RGBA8) or 16.6 MB (RGBA16F) per 1080p
+ * frame instead of 33.2 MB.
+ *   URT_FORMAT_RGBA32F     as urt_texture_read_begin
+ *   URT_FORMAT_RGBA8_SRGB  bytes R, G, B, A per pixel: colour through the sRGB transfer function (the project renders in linear colour
+ *                          space, ProjectSettings/ProjectSettings.asset:50, so a blit into an 8-bit back buffer encodes) — exactly the
+ *                          bytes of urt_host_encode_srgb8 / urt_host_write_png; alpha as UNORM8
+ *   URT_FORMAT_RGBA16F     four IEEE halfs per pixel, round to nearest even (a camera with allowHDR: ARGBHalf)
+ * end_format: *out_pixels = the pinned host image (row 0 = bottom), *out_bytes (may be NULL) its size.  Tickets of converted images
+ * must be ended with urt_texture_read_end_format. */
+enum { URT_FORMAT_RGBA32F = 0, URT_FORMAT_RGBA8_SRGB = 1, URT_FORMAT_RGBA16F = 2 };
+URT_API int urt_texture_read_begin_format(urt_context* ctx, urt_handle texture, int format, uint64_t* out_ticket);
+URT_API int urt_texture_read_end_format(urt_context* ctx, uint64_t ticket, const void** out_pixels, size_t* out_bytes);
 URT_API int urt_texture_get_info(urt_context* ctx, urt_handle texture, int* out_width, int* out_height,
                                  void** out_device_ptr);
 /* texture.Release()                                                  RM:830-831 */
@@ -314,6 +327,11 @@ URT_API int urt_host_resize_rgba(const float* src, int width, int height, float*
 URT_API int urt_host_write_pfm(const char* path, const float* rgba, int width, int height);
 /* RGBA32F linear image -> 8-bit sRGB .png (what ScreenCapture.CaptureScreenshot produces for RM:762). */
 URT_API int urt_host_write_png(const char* path, const float* rgba, int width, int height);
+/* The PNG writer's pixel encoding on its own: RGBA32F linear -> RGBA8 (colour: sRGB transfer function, clamped, NaN -> 0; alpha: UNORM8),
+ * and the encoder as the step function it is: out256[k] = the smallest float whose code is >= k (out256[0] = -inf) — the table the GPU
+ * encoder of urt_texture_read_begin_format searches. */
+URT_API int urt_host_encode_srgb8(const float* rgba, size_t n_pixels, unsigned char* out_rgba8);
+URT_API int urt_host_srgb8_first_floats(float* out256);
 URT_API const char* urt_host_io_last_error(void);
 
 /* ---- host-side debug log and BVH inspection (no GPU needed) ------------------ */

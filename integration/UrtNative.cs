@@ -53,6 +53,9 @@ internal static class UrtNative {
     [DllImport(Lib)] internal static extern int urt_texture_unpack_rows_on(IntPtr ctx, ulong texture, int firstGroupRow, int rowStride, IntPtr deviceSrc, IntPtr hipStream);
     [DllImport(Lib)] internal static extern int urt_texture_read_begin(IntPtr ctx, ulong texture, out ulong ticket);
     [DllImport(Lib)] internal static extern int urt_texture_read_end(IntPtr ctx, ulong ticket, out IntPtr rgba);   // pinned host image, width x height x 4 floats
+    internal const int URT_FORMAT_RGBA32F = 0, URT_FORMAT_RGBA8_SRGB = 1, URT_FORMAT_RGBA16F = 2;
+    [DllImport(Lib)] internal static extern int urt_texture_read_begin_format(IntPtr ctx, ulong texture, int format, out ulong ticket);   // converted on the GPU to the destination's format
+    [DllImport(Lib)] internal static extern int urt_texture_read_end_format(IntPtr ctx, ulong ticket, out IntPtr pixels, out UIntPtr bytes);
     [DllImport(Lib)] internal static extern int urt_texture_pack_rows_rgb(IntPtr ctx, ulong texture, int firstGroupRow, int rowStride, IntPtr deviceDst, out ulong bytes);
     [DllImport(Lib)] internal static extern int urt_texture_unpack_rows_rgb(IntPtr ctx, ulong texture, int firstGroupRow, int rowStride, IntPtr deviceSrc, float alpha, IntPtr hipStream);
 
@@ -106,6 +109,8 @@ internal static class UrtNative {
     [DllImport(Lib)] internal static extern int urt_host_load_hdr(string path, out int width, out int height, [Out] float[] rgba, UIntPtr capacityFloats);
     [DllImport(Lib)] internal static extern int urt_host_write_pfm(string path, float[] rgba, int width, int height);
     [DllImport(Lib)] internal static extern int urt_host_write_png(string path, float[] rgba, int width, int height);
+    [DllImport(Lib)] internal static extern int urt_host_encode_srgb8(float[] rgba, UIntPtr nPixels, byte[] outRgba8);
+    [DllImport(Lib)] internal static extern int urt_host_srgb8_first_floats(float[] out256);
     [DllImport(Lib)] internal static extern int urt_host_log(string path, int debugLevel, int level, string text);
     [DllImport(Lib)] internal static extern int urt_host_log_scene_counts(string path, int debugLevel, int nSpheres, int nMeshObjects, int nVertices, int nIndices, int nNormals);
     [DllImport(Lib)] internal static extern int urt_host_log_tree_report(string path, int debugLevel, int nMeshObjects, int meshDepth, int meshRealLength, int nSpheres, int sphereDepth, int sphereRealLength);

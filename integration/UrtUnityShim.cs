@@ -134,16 +134,21 @@ public static class UrtGraphics {
     static ulong pendingTicket = 0;
     public static void BlitPipelined(UrtRenderTexture src, RenderTexture unityDestination, ref Texture2D staging) {
         if (UrtDevice.IsGroup) throw new NotSupportedException("pipelined readback is per device: gather to rank 0's image first");
-        if (staging == null || staging.width != src.width || staging.height != src.height)
-            staging = new Texture2D(src.width, src.height, TextureFormat.RGBAFloat, false, true);
+        // The image crosses the bus in the destination's OWN format, converted on the GPU (csrc/present.hip): an 8-bit back buffer of this
+        // linear-colour-space project gets sRGB-encoded bytes (8.3 MB per 1080p frame instead of 33.2 MB), an HDR camera's ARGBHalf halfs.
+        bool hdr = unityDestination != null && unityDestination.format == RenderTextureFormat.ARGBHalf;
+        TextureFormat tf = hdr ? TextureFormat.RGBAHalf : TextureFormat.RGBA32;
+        if (staging == null || staging.width != src.width || staging.height != src.height || staging.format != tf)
+            staging = new Texture2D(src.width, src.height, tf, false, /* linear: */ hdr);   // RGBA32 declared sRGB: sampling decodes, the blit re-encodes
         if (pendingTicket != 0) {
-            IntPtr rgba;
-            UrtDevice.Check(UrtNative.urt_texture_read_end(UrtDevice.Handle, pendingTicket, out rgba));
-            staging.LoadRawTextureData(rgba, src.width * src.height * 16);
+            IntPtr pixels; UIntPtr bytes;
+            UrtDevice.Check(UrtNative.urt_texture_read_end_format(UrtDevice.Handle, pendingTicket, out pixels, out bytes));
+            staging.LoadRawTextureData(pixels, (int)bytes.ToUInt32());
             staging.Apply(false);
             Graphics.Blit(staging, unityDestination);
         }
-        UrtDevice.Check(UrtNative.urt_texture_read_begin(UrtDevice.Handle, src.handle, out pendingTicket));
+        UrtDevice.Check(UrtNative.urt_texture_read_begin_format(UrtDevice.Handle, src.handle,
+                                                                hdr ? UrtNative.URT_FORMAT_RGBA16F : UrtNative.URT_FORMAT_RGBA8_SRGB, out pendingTicket));
     }
     /// Present through Unity: read the image back (this submits and waits) and hand it to a Unity RenderTexture.
     public static void Blit(UrtRenderTexture src, RenderTexture unityDestination, ref Texture2D staging, ref float[] managed) {

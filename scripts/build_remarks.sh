@@ -10,7 +10,7 @@ if [ -n "$KERNELS_ONLY" ]; then
 else
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -fvisibility=hidden -pthread -Xarch_host -march=x86-64-v3 -Xarch_device -fno-slp-vectorize \
   -Wall -Wno-unused-function -Rpass-analysis=kernel-resource-usage "$@" -o "$OUT" \
-  csrc/kernels.hip csrc/lbvh.hip csrc/refit.hip csrc/qnodes.hip csrc/cullflags.hip csrc/context.cpp csrc/blas_builder.cpp csrc/host_scene.cpp csrc/host_io.cpp csrc/host_debug.cpp csrc/group.cpp 2> /tmp/urt_remarks.log
+  csrc/kernels.hip csrc/lbvh.hip csrc/refit.hip csrc/qnodes.hip csrc/cullflags.hip csrc/present.hip csrc/context.cpp csrc/blas_builder.cpp csrc/host_scene.cpp csrc/host_io.cpp csrc/host_debug.cpp csrc/group.cpp 2> /tmp/urt_remarks.log
 fi
 rc=$?
 grep -E "error" -A6 /tmp/urt_remarks.log | head -40

@@ -135,6 +135,57 @@ def test_write_png_is_a_valid_srgb_png(built_library, tmp_path):
     assert np.array_equal(np.asarray(Image.open(p)), px)
 
 
+def present_probe_image():
+    """Floats around every step of the 8-bit sRGB encoder (+-300 representable neighbours of each code's first float), the specials
+    (NaN, +-inf, +-0, denormals, negatives, huge) and a uniform random fill; (rows, 601, 4) float32, every channel exercised."""
+    first = host_io.srgb8_first_floats()
+    bits = first[1:].view(np.uint32).astype(np.int64)
+    near = (bits[:, None] + np.arange(-300, 301)[None, :]).astype(np.uint32).view(np.float32)           # (255, 601)
+    rng = np.random.default_rng(11)
+    special = np.array([np.nan, np.inf, -np.inf, 0.0, -0.0, 1e-45, 1e-40, -1e-40, -1.0, 1.0, np.nextafter(np.float32(1), np.float32(0)), 65504.0, 65520.0,
+                        1e30, 6.1e-5, 5.96e-8, 2.98e-8, 2.9802325e-08, 0.5, 1.0 / 510.0, 253.5 / 255.0], np.float32)
+    img = np.zeros((255 + 8, 601, 4), np.float32)
+    img[:255, :, 0] = near
+    img[:255, :, 1] = near[::-1]
+    img[:255, :, 2] = np.roll(near, 7, axis=0)
+    img[:255, :, 3] = (np.arange(255 * 601, dtype=np.float64).reshape(255, 601) / (255 * 601 - 1)).astype(np.float32)   # alpha ramp: every UNORM8 code
+    img[255:] = rng.uniform(-0.25, 1.5, (8, 601, 4)).astype(np.float32)
+    img[255, :special.size, :] = special[:, None]
+    img[256, :255, 3] = ((np.arange(255) + 0.5) / 255.0).astype(np.float32)                                   # alpha at the rounding ties
+    return img
+
+
+def test_srgb8_encoder_and_its_step_table(built_library, tmp_path):
+    """urt_host_encode_srgb8 (the PNG writer's pixel encoding; what RenderTexture.ReadBegin("RGBA8_SRGB") delivers from the GPU) against
+    (a) an independent double-precision restatement of the sRGB transfer function — equal except where float pow() lands within
+    rounding of a code boundary (at most four of the 601 floats nearest to each boundary, none elsewhere); (b) the PNG writer's
+    own bytes; (c) the step table urt_host_srgb8_first_floats: code(x) == number of steps at or below x, for the neighbours of every step."""
+    img = present_probe_image()
+    got = host_io.encode_srgb8(img)
+    x = img[..., :3].astype(np.float64)
+    with np.errstate(invalid="ignore"):
+        s = np.where(x <= 0.0031308, 12.92 * x, 1.055 * np.power(np.maximum(x, 0), 1 / 2.4) - 0.055)
+        want = np.where(np.isnan(x) | (x <= 0), 0, np.where(x >= 1, 255, np.floor(s * 255 + 0.5))).astype(np.int64)
+    d = np.abs(got[..., :3].astype(np.int64) - want)
+    # float32 evaluation (powf, the multiply-add, x 255) moves a boundary by a few representable floats against the double evaluation
+    assert d.max() <= 1 and int((d[:255, :, 0] != 0).sum(axis=1).max()) <= 4, (int(d.max()), int((d[:255, :, 0] != 0).sum(axis=1).max()))
+    assert int((d[257:] != 0).sum()) <= 3                       # 10,818 random values: the chance to sit within four floats of a boundary is 1e-4 each
+    a = img[..., 3].astype(np.float64)
+    with np.errstate(invalid="ignore"):
+        v = (img[..., 3] * np.float32(255.0)).astype(np.float64)   # the product is rounded to float32 first (urt_host_encode_srgb8)
+        wa = np.where(np.isnan(a) | (a <= 0), 0, np.where(a >= 1, 255, np.floor(v + 0.5))).astype(np.int64)
+    assert np.array_equal(got[..., 3].astype(np.int64), wa)
+    p = str(tmp_path / "probe.png")
+    host_io.write_png(p, img)
+    from PIL import Image
+    assert np.array_equal(np.asarray(Image.open(p))[::-1], got[..., :3])     # PNG rows run top to bottom
+    first = host_io.srgb8_first_floats()
+    assert first[0] == -np.inf and np.all(np.diff(first[1:]) > 0) and first[255] < 1.0
+    codes = np.searchsorted(first[1:], img[..., :3], side="right")           # steps at or below x (NaN sorts last: handled below)
+    codes = np.where(np.isnan(img[..., :3]), 0, codes)
+    assert np.array_equal(codes.astype(np.uint8), got[..., :3])
+
+
 def test_mitchell_resize_and_sky_import_limit(built_library, tmp_path):
     """urt_host_resize_rgba: constant images stay constant (normalised weights), a linear ramp stays linear away from the edges,
     energy is preserved on a 2:1 downscale; load_sky applies the importer's maxTextureSize (Assets/Skyboxes/*.hdr.meta:36)."""

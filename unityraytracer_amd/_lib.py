@@ -18,12 +18,12 @@ ERROR_NAMES = {1: "INVALID_ARGUMENT", 2: "INVALID_HANDLE", 3: "NO_DEVICE", 4: "H
 ABI_SYMBOLS = [
     "urt_abi_version", "urt_device_count", "urt_context_create", "urt_context_destroy", "urt_last_error", "urt_context_set_stream",
     "urt_synchronize", "urt_flush", "urt_buffer_create", "urt_buffer_set_data", "urt_buffer_get_info", "urt_buffer_release", "urt_texture_create",
-    "urt_texture_create_external", "urt_texture_set_pixels", "urt_texture_get_pixels", "urt_texture_get_info", "urt_texture_read_begin", "urt_texture_read_end", "urt_texture_release",
+    "urt_texture_create_external", "urt_texture_set_pixels", "urt_texture_get_pixels", "urt_texture_get_info", "urt_texture_read_begin", "urt_texture_read_end", "urt_texture_read_begin_format", "urt_texture_read_end_format", "urt_texture_release",
     "urt_shader_set_buffer", "urt_shader_set_texture", "urt_shader_set_matrix", "urt_shader_set_vector", "urt_shader_set_float",
     "urt_shader_set_int", "urt_shader_dispatch", "urt_shader_dispatch_rows", "urt_blit_add", "urt_blit", "urt_texture_pack_rows",
     "urt_texture_unpack_rows", "urt_texture_unpack_rows_on", "urt_texture_pack_rows_rgb", "urt_texture_unpack_rows_rgb", "urt_set_option", "urt_get_counters", "urt_reset_counters", "urt_debug_build_blas", "urt_debug_get_blas", "urt_debug_blas_cache_stats",
     "urt_debug_scene_info", "urt_debug_launch_info", "urt_debug_read_scene_blas", "urt_debug_serve_stats", "urt_debug_refit_stats", "urt_debug_build_walk_table", "urt_host_compute_normals", "urt_host_mesh_leaf_bounds", "urt_host_sphere_leaf_bounds", "urt_host_object_bvh_length",
-    "urt_host_build_object_bvh", "urt_host_build_object_bvh_pairing", "urt_host_last_error", "urt_host_load_hdr", "urt_host_write_pfm", "urt_host_write_png",
+    "urt_host_build_object_bvh", "urt_host_build_object_bvh_pairing", "urt_host_last_error", "urt_host_load_hdr", "urt_host_write_pfm", "urt_host_write_png", "urt_host_encode_srgb8", "urt_host_srgb8_first_floats",
     "urt_host_resize_rgba", "urt_host_io_last_error", "urt_host_log", "urt_host_log_scene_counts", "urt_host_log_tree_report", "urt_host_dump_bvh", "urt_host_dump_normals",
     "urt_host_debug_last_error",
     "urt_group_create", "urt_group_destroy", "urt_group_size", "urt_group_context", "urt_group_last_error", "urt_group_buffer_create",
@@ -102,6 +102,8 @@ def load():
         "urt_texture_get_info": ([vp, u64, pi, pi, C.POINTER(vp)], i),
         "urt_texture_read_begin": ([vp, u64, C.POINTER(u64)], i),
         "urt_texture_read_end": ([vp, u64, C.POINTER(C.POINTER(C.c_float))], i),
+        "urt_texture_read_begin_format": ([vp, u64, i, C.POINTER(u64)], i),
+        "urt_texture_read_end_format": ([vp, u64, C.POINTER(vp), C.POINTER(C.c_size_t)], i),
         "urt_texture_release": ([vp, u64], i),
         "urt_shader_set_buffer": ([vp, i, C.c_char_p, u64], i),
         "urt_shader_set_texture": ([vp, i, C.c_char_p, u64], i),
@@ -141,6 +143,8 @@ def load():
         "urt_host_load_hdr": ([C.c_char_p, pi, pi, vp, C.c_size_t], i),
         "urt_host_write_pfm": ([C.c_char_p, vp, i, i], i),
         "urt_host_write_png": ([C.c_char_p, vp, i, i], i),
+        "urt_host_encode_srgb8": ([vp, C.c_size_t, vp], i),
+        "urt_host_srgb8_first_floats": ([vp], i),
         "urt_host_resize_rgba": ([vp, i, i, vp, i, i], i),
         "urt_host_io_last_error": ([], C.c_char_p),
         "urt_host_log": ([C.c_char_p, i, i, C.c_char_p], i),

@@ -18,7 +18,7 @@ HIPCC_FLAGS = [
     "-Xarch_device", "-fno-slp-vectorize",   # v_pk_fma_f32 issues at half rate on gfx950 and its operand pairs cost moves: -0.5 .. -1.4 % frame time (r3_ab_cnodes_noslp.log)
     "-Wall", "-Wno-unused-function",
 ]
-SOURCES = ["kernels.hip", "lbvh.hip", "refit.hip", "qnodes.hip", "cullflags.hip", "context.cpp", "blas_builder.cpp", "host_scene.cpp", "host_io.cpp", "host_debug.cpp", "group.cpp"]
+SOURCES = ["kernels.hip", "lbvh.hip", "refit.hip", "qnodes.hip", "cullflags.hip", "present.hip", "context.cpp", "blas_builder.cpp", "host_scene.cpp", "host_io.cpp", "host_debug.cpp", "group.cpp"]
 
 
 def _newer(target: str, deps) -> bool:

@@ -27,6 +27,7 @@
 #include "refit.h"
 #include "qnodes.h"
 #include "cullflags.h"
+#include "present.h"
 #include "urt_device.h"
 
 #include <chrono>
@@ -198,7 +199,8 @@ struct urt_context {
   int last_builder = 0;                     // the triangle-BVH builder the last full scene preparation used (0..3)
   // pipelined readback (urt_texture_read_begin / _end): kReadSlots snapshots in flight, each a device copy + a pinned host image
   static constexpr int kReadSlots = 3;
-  struct ReadSlot { float4* dev = nullptr; float4* host = nullptr; size_t pixels = 0; hipEvent_t snap = nullptr, done = nullptr; bool busy = false; uint64_t ticket = 0; } rslot[kReadSlots];
+  struct ReadSlot { float4* dev = nullptr; float4* host = nullptr; size_t pixels = 0; size_t bytes = 0; int format = 0; hipEvent_t snap = nullptr, done = nullptr; bool busy = false; uint64_t ticket = 0; } rslot[kReadSlots];
+  float* srgb_first = nullptr;                // device: first float of every 8-bit sRGB code (csrc/present.hip), made at the first RGBA8 readback
   hipStream_t copy_stream = nullptr;
   uint64_t read_next = 0;
   int opt_lbvh_slack = 6;                   // blas_builder 2: levels of slack in the depth budget (csrc/lbvh.hip k_td_level)
@@ -1398,6 +1400,7 @@ int urt_context_destroy(urt_context* ctx) {
     if (r.host) (void)hipHostFree(r.host);
   }
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+  if (ctx->srgb_first) (void)hipFree(ctx->srgb_first);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
   return URT_OK;
@@ -1546,9 +1549,15 @@ int urt_texture_get_pixels(urt_context* ctx, urt_handle texture, float* rgba) {
 // Pipelined readback.  begin: the image as it is at this point of the program order is snapshot on the render stream (a device-to-device
 // copy: 33 MB at 1080p, ~20 us) and travels to a pinned host image on a stream of its own, so the frames dispatched AFTER the call render
 // while it is on the PCIe bus; end: waits for that one copy and hands the pinned image out.
-int urt_texture_read_begin(urt_context* ctx, urt_handle texture, uint64_t* out_ticket) {
+int urt_texture_read_begin(urt_context* ctx, urt_handle texture, uint64_t* out_ticket) { return urt_texture_read_begin_format(ctx, texture, URT_FORMAT_RGBA32F, out_ticket); }
+
+// ... in the format of the host's `destination` (csrc/present.hip): the snapshot on the render stream IS the conversion kernel (16 B read,
+// 4 or 8 B written per pixel), and only the converted image crosses the bus.
+int urt_texture_read_begin_format(urt_context* ctx, urt_handle texture, int format, uint64_t* out_ticket) {
   if (!ctx) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "ctx is NULL");
   if (!out_ticket) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "out_ticket is NULL");
+  const size_t bpp = urtd::format_pixel_bytes(format);
+  if (!bpp) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "urt_texture_read_begin_format: format must be URT_FORMAT_RGBA32F, _RGBA8_SRGB or _RGBA16F");
   Texture* t = find_texture(ctx, texture);
   if (!t) return fail(ctx, URT_ERR_INVALID_HANDLE, "unknown texture handle");
   URT_HIP(ctx, hipSetDevice(ctx->device));
@@ -1568,10 +1577,22 @@ int urt_texture_read_begin(urt_context* ctx, urt_handle texture, uint64_t* out_t
     r.pixels = px;
   }
   if (!r.snap) { URT_HIP(ctx, hipEventCreateWithFlags(&r.snap, hipEventDisableTiming)); URT_HIP(ctx, hipEventCreateWithFlags(&r.done, hipEventDisableTiming)); }
-  URT_HIP(ctx, hipMemcpyAsync(r.dev, t->dev, px * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
+  if (format == urtd::kFormatRGBA32F) {
+    URT_HIP(ctx, hipMemcpyAsync(r.dev, t->dev, px * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
+  } else {
+    if (format == urtd::kFormatRGBA8sRGB && !ctx->srgb_first) {
+      float first[urtd::kSrgbCodes];
+      (void)urt_host_srgb8_first_floats(first);
+      URT_HIP(ctx, hipMalloc((void**)&ctx->srgb_first, sizeof(first)));
+      URT_HIP(ctx, hipMemcpy(ctx->srgb_first, first, sizeof(first), hipMemcpyHostToDevice));
+    }
+    URT_HIP(ctx, urtd::launch_encode(t->dev, r.dev, px, format, ctx->srgb_first, ctx->stream));
+  }
+  r.format = format;
+  r.bytes = px * bpp;
   URT_HIP(ctx, hipEventRecord(r.snap, ctx->stream));
   URT_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, r.snap, 0));
-  URT_HIP(ctx, hipMemcpyAsync(r.host, r.dev, px * sizeof(float4), hipMemcpyDeviceToHost, ctx->copy_stream));
+  URT_HIP(ctx, hipMemcpyAsync(r.host, r.dev, r.bytes, hipMemcpyDeviceToHost, ctx->copy_stream));
   URT_HIP(ctx, hipEventRecord(r.done, ctx->copy_stream));
   r.busy = true;
   r.ticket = ++ctx->read_next;                               // tickets start at 1; slot = (ticket - 1) % kReadSlots
@@ -1583,11 +1604,24 @@ int urt_texture_read_end(urt_context* ctx, uint64_t ticket, const float** out_rg
   if (!ctx) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "ctx is NULL");
   if (!out_rgba || ticket == 0) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "bad ticket / out_rgba is NULL");
   urt_context::ReadSlot& r = ctx->rslot[(ticket - 1) % urt_context::kReadSlots];
+  if (r.busy && r.ticket == ticket && r.format != urtd::kFormatRGBA32F)
+    return fail(ctx, URT_ERR_INVALID_ARGUMENT, "urt_texture_read_end: this ticket holds a converted image — end it with urt_texture_read_end_format");
+  const void* p = nullptr;
+  int rc = urt_texture_read_end_format(ctx, ticket, &p, nullptr);
+  if (rc == URT_OK || rc == URT_ERR_WATCHDOG) *out_rgba = (const float*)p;
+  return rc;
+}
+
+int urt_texture_read_end_format(urt_context* ctx, uint64_t ticket, const void** out_pixels, size_t* out_bytes) {
+  if (!ctx) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  if (!out_pixels || ticket == 0) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "bad ticket / out_pixels is NULL");
+  urt_context::ReadSlot& r = ctx->rslot[(ticket - 1) % urt_context::kReadSlots];
   if (!r.busy || r.ticket != ticket) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "urt_texture_read_end: this ticket is not in flight");
   URT_HIP(ctx, hipSetDevice(ctx->device));
   URT_HIP(ctx, hipEventSynchronize(r.done));
   r.busy = false;
-  *out_rgba = (const float*)r.host;                          // valid until the third urt_texture_read_begin after this one
+  *out_pixels = r.host;                                      // valid until the third urt_texture_read_begin after this one
+  if (out_bytes) *out_bytes = r.bytes;
   return check_watchdog(ctx);
 }
 

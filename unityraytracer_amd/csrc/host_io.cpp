@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -63,9 +64,44 @@ inline unsigned char srgb8(float x) {           // linear -> sRGB transfer, clam
   return (unsigned char)std::lround(s * 255.0f);
 }
 
+inline unsigned char unorm8(float a) {          // alpha: linear UNORM8
+  if (!(a > 0.0f)) return 0;
+  if (a >= 1.0f) return 255;
+  return (unsigned char)std::lround(a * 255.0f);
+}
+
 }  // namespace
 
 extern "C" {
+
+// RGBA32F linear -> RGBA8: colour through the sRGB transfer function (the PNG writer's codes), alpha as UNORM8.  The GPU encoder of
+// urt_texture_read_begin_format (csrc/present.hip) produces these bytes.
+int urt_host_encode_srgb8(const float* rgba, size_t n_pixels, unsigned char* out_rgba8) {
+  if ((!rgba || !out_rgba8) && n_pixels) return -1;
+  for (size_t i = 0; i < n_pixels; i++) {
+    out_rgba8[4 * i] = srgb8(rgba[4 * i]); out_rgba8[4 * i + 1] = srgb8(rgba[4 * i + 1]); out_rgba8[4 * i + 2] = srgb8(rgba[4 * i + 2]);
+    out_rgba8[4 * i + 3] = unorm8(rgba[4 * i + 3]);
+  }
+  return 0;
+}
+
+// out[k], k = 1..255: the smallest float whose sRGB code is >= k (out[0] = -inf): the encoder as the step function it is.  Bisection
+// over the bit patterns of the positive floats (ordered like the floats); the encoder is monotone — tests/test_host_io.py checks the
+// table against the encoder around every step.
+int urt_host_srgb8_first_floats(float* out256) {
+  if (!out256) return -1;
+  out256[0] = -std::numeric_limits<float>::infinity();
+  for (int k = 1; k < 256; k++) {
+    uint32_t lo = 0, hi = 0x3f800000u;               // code(+0) = 0 < k <= 255 = code(1.0f)
+    while (hi - lo > 1) {
+      uint32_t mid = lo + (hi - lo) / 2;
+      float x; std::memcpy(&x, &mid, 4);
+      if (srgb8(x) >= k) hi = mid; else lo = mid;
+    }
+    std::memcpy(&out256[k], &hi, 4);
+  }
+  return 0;
+}
 
 // Downscale to the importer's `maxTextureSize` (Assets/Skyboxes/*.hdr.meta:36 = 2048) with the resize filter the .meta names
 // (platformSettings.resizeAlgorithm: 0 = Mitchell): separable Mitchell-Netravali (B = C = 1/3), the kernel widened by the scale

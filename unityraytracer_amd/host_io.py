@@ -38,6 +38,24 @@ def write_png(path: str, rgba: np.ndarray):
     _check(lib, lib.urt_host_write_png(path.encode(), a.ctypes.data_as(C.c_void_p), a.shape[1], a.shape[0]))
 
 
+def encode_srgb8(rgba: np.ndarray) -> np.ndarray:
+    """Linear RGBA32F -> RGBA8, colour through the sRGB transfer function, alpha UNORM8: write_png's pixel encoding on its own
+    (include/urt.h urt_host_encode_srgb8) — the bytes RenderTexture.ReadBegin("RGBA8_SRGB") delivers."""
+    lib = _lib.load()
+    a = np.ascontiguousarray(rgba, dtype=np.float32)
+    out = np.empty(a.shape, dtype=np.uint8)
+    _check(lib, lib.urt_host_encode_srgb8(a.ctypes.data_as(C.c_void_p), a.size // 4, out.ctypes.data_as(C.c_void_p)))
+    return out
+
+
+def srgb8_first_floats() -> np.ndarray:
+    """[k] = the smallest float32 whose sRGB code is >= k ([0] = -inf): the step table the GPU encoder searches."""
+    lib = _lib.load()
+    out = np.empty(256, dtype=np.float32)
+    _check(lib, lib.urt_host_srgb8_first_floats(out.ctypes.data_as(C.c_void_p)))
+    return out
+
+
 def resize(rgba: np.ndarray, new_width: int, new_height: int) -> np.ndarray:
     """Separable Mitchell-Netravali resize of an (H, W, 4) float32 image (include/urt.h urt_host_resize_rgba)."""
     lib = _lib.load()

@@ -230,18 +230,25 @@ class RenderTexture:
         self.ctx.check(self.ctx.lib.urt_texture_get_pixels(self.ctx._h, self.handle, out.ctypes.data_as(C.c_void_p)))
         return out
 
-    def ReadBegin(self) -> int:
-        """Start a pipelined readback of the image as it is now (include/urt.h urt_texture_read_begin); returns a ticket."""
+    FORMATS = {"RGBA32F": (0, np.float32), "RGBA8_SRGB": (1, np.uint8), "RGBA16F": (2, np.float16)}   # include/urt.h URT_FORMAT_*
+
+    def ReadBegin(self, format: str = "RGBA32F") -> int:
+        """Start a pipelined readback of the image as it is now (include/urt.h urt_texture_read_begin_format), converted on the GPU to
+        `format` ("RGBA32F", "RGBA8_SRGB": what an 8-bit back buffer holds after RM:819, "RGBA16F"); returns a ticket."""
         t = C.c_uint64()
-        self.ctx.check(self.ctx.lib.urt_texture_read_begin(self.ctx._h, self.handle, C.byref(t)))
+        self.ctx.check(self.ctx.lib.urt_texture_read_begin_format(self.ctx._h, self.handle, self.FORMATS[format][0], C.byref(t)))
+        self._read_formats = getattr(self, "_read_formats", {})
+        self._read_formats[t.value] = format
         return t.value
 
     def ReadEnd(self, ticket: int, copy: bool = True) -> np.ndarray:
-        """Wait for that readback; the image as (height, width, 4) float32 — a copy, or (copy=False) a view of the library's pinned
-        buffer that stays valid until the third ReadBegin after the ticket's."""
-        p = C.POINTER(C.c_float)()
-        self.ctx.check(self.ctx.lib.urt_texture_read_end(self.ctx._h, C.c_uint64(ticket), C.byref(p)))
-        a = np.ctypeslib.as_array(p, shape=(self.height, self.width, 4))
+        """Wait for that readback; the image as (height, width, 4) of the ticket's format — a copy, or (copy=False) a view of the
+        library's pinned buffer that stays valid until the third ReadBegin after the ticket's."""
+        dtype = self.FORMATS[getattr(self, "_read_formats", {}).pop(ticket, "RGBA32F")][1]
+        p, n = C.c_void_p(), C.c_size_t()
+        self.ctx.check(self.ctx.lib.urt_texture_read_end_format(self.ctx._h, C.c_uint64(ticket), C.byref(p), C.byref(n)))
+        assert n.value == self.height * self.width * 4 * np.dtype(dtype).itemsize
+        a = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n.value,)).view(dtype).reshape(self.height, self.width, 4)
         return a.copy() if copy else a
 
     def device_ptr(self) -> int:
