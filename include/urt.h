@@ -211,6 +211,13 @@ typedef struct urt_counters {
  *                        beyond the ground-plane hit, by a margin, is not intersected although the reference would (RS:294-326 keeps
  *                        testing every popped leaf once `tests` is set; such an object cannot hold the closest hit).  Only leaves whose
  *                        box the library has verified to contain the object's triangles; 0 = the reference's literal work),
+ *          "overlap_launches" (0 off / 1 auto (default) / 2 always: launches of up to 8 frames — a host that submits every frame on its own,
+ *                              urt_flush or a present per frame — alternate between two trace streams of the library's own and take their
+ *                              Result slots round-robin, so that the next launch fills the wave slots the draining waves of the previous one
+ *                              give back (C3, one frame per submission: 0.61 -> 0.50 ms per frame); blends, presents and readbacks stay on
+ *                              the context's stream in program order.  Auto: not while a pipelined readback is in flight — a host that
+ *                              waits for finished frames gets them later when two launches share the chip (+6 % C3, +21 % C2 with two
+ *                              tickets in flight).  Only on the library's own stream),
  *          "frames_per_launch" (0 = auto: own stream -> up to 64 frames per launch (fewer if their Result slots exceed 8 GiB), caller's stream -> 1;
  *                               1 = every dispatch is its own launch; 2..64 = batch that many, also on a caller's stream),
  *          "count_stats" (0/1: per-dispatch traversal counters, slower build of the kernel),
@@ -389,6 +396,10 @@ typedef struct urt_launch_info {
   int slab_frames, slab_frames_max, slab_out_of_memory;
   int experiment;             /* 1: the library is an A/B / probe / diagnostic build (negative urt_abi_version) */
   int blas_builder;           /* the triangle-BVH builder the scene's last full preparation used (0..3; what "blas_builder" -1 = auto resolved to) */
+  int trace_stream;           /* 0: launched on the context's stream; 1 / 2: on one of the library's two trace streams (option "overlap_launches") */
+  int slab_base;              /* first Result slot of the launch */
+  int overlapped;             /* 1: the launch did not wait for the previous launch (it waited for the main stream as of the previous submission) */
+  int overlapped_launches;    /* such launches since the context was created */
 } urt_launch_info;
 URT_API int urt_debug_launch_info(urt_context* ctx, urt_launch_info* out_info);
 URT_API int urt_debug_read_scene_blas(urt_context* ctx, float* nodes, int32_t* tri_index, int32_t* mesh_root);

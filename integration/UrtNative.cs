@@ -126,7 +126,7 @@ internal static class UrtNative {
     [DllImport(Lib)] internal static extern int urt_debug_build_blas(IntPtr meshObjects, int nMeshes, float[] vertices, int nVertices, int[] indices, int nIndices, out int nNodes, out int nTris, out int maxDepth);
     [DllImport(Lib)] internal static extern int urt_debug_get_blas([Out] float[] nodes, [Out] int[] triIndex, [Out] int[] meshRoot, [Out] int[] meshFirstTri);
     [DllImport(Lib)] internal static extern int urt_debug_scene_info(IntPtr ctx, out int nNodes, out int nTris, out int maxDepth, out float prepareMs);
-    [DllImport(Lib)] internal static extern int urt_debug_launch_info(IntPtr ctx, [Out] byte[] launchInfo176);   // urt_launch_info: char kernel[96] + 20 ints
+    [DllImport(Lib)] internal static extern int urt_debug_launch_info(IntPtr ctx, [Out] byte[] launchInfo192);   // urt_launch_info: char kernel[96] + 24 ints
     [DllImport(Lib)] internal static extern int urt_debug_read_scene_blas(IntPtr ctx, [Out] float[] nodes, [Out] int[] triIndex, [Out] int[] meshRoot);
     [DllImport(Lib)] internal static extern int urt_debug_blas_cache_stats(IntPtr ctx, out ulong reused, out ulong built);
     [DllImport(Lib)] internal static extern int urt_debug_serve_stats(IntPtr ctx, [Out] ulong[] out6);

@@ -48,7 +48,7 @@ class LaunchInfo(C.Structure):
     _fields_ = [("kernel", C.c_char * 96)] + [(n, C.c_int) for n in (
         "kernel_mode", "front_mode", "count_stats", "n_blocks", "block_threads", "lds_bytes", "waves_per_cu", "n_frames", "frame_group",
         "xcd_run", "tile_order", "top_nodes", "tlas_stack", "blas_stack", "lds_tables", "slab_frames", "slab_frames_max",
-        "slab_out_of_memory", "experiment", "blas_builder")]
+        "slab_out_of_memory", "experiment", "blas_builder", "trace_stream", "slab_base", "overlapped", "overlapped_launches")]
 
     def as_dict(self):
         d = {n: getattr(self, n) for n, _ in self._fields_}

@@ -208,7 +208,22 @@ struct urt_context {
   int32_t* d_mesh_leaf = nullptr;           // per MeshObject: its heap leaf, or < 0 (in scene_allocs)
   size_t cap_mesh_leaf = 0;
   size_t slab_oom_stride = 0;               // image size (pixels) for which not even two slots could be allocated
+  // Overlapped launches (option "overlap_launches", flush_pending): a host that SUBMITS every frame (urt_flush, a present into an external
+  // texture) produces one-frame launches, and a one-frame launch is mostly ramp and drain.  Small launches therefore alternate between two trace streams and take their Result slots
+  // round-robin from the slab, so that launch L+1 fills the wave slots launch L's draining waves give back; the blends / presents /
+  // readbacks stay on the main stream, in program order, each behind its own launch.
+  static constexpr int kOverlapFrames = 8;  // launches of up to this many frames take part
+  int opt_overlap = 1;
+  hipStream_t trace_q[2] = {nullptr, nullptr};
+  hipEvent_t trace_done[2] = {nullptr, nullptr}, pre_ev[2] = {nullptr, nullptr}, dep_ev = nullptr;
+  unsigned int* d_next2 = nullptr;          // the second launch in flight needs work counters of its own
+  unsigned int trace_parity = 0;
+  bool main_touched = true;                 // something other than the frame loop's own blends / presents / readbacks was enqueued on the main stream since the last launch
+  int slab_cursor = 0, prev_base = 0, prev_n = 0;
+  uint64_t overlapped_launches = 0;
 };
+
+namespace { inline hipStream_t touch(urt_context* ctx) { ctx->main_touched = true; return ctx->stream; } }
 
 namespace {
 
@@ -250,7 +265,7 @@ int check_watchdog(urt_context* ctx) {
 }
 
 void free_scene(urt_context* ctx) {
-  if (!ctx->scene_allocs.empty()) (void)hipStreamSynchronize(ctx->stream);   // queued kernels may still read them
+  if (!ctx->scene_allocs.empty()) (void)hipStreamSynchronize(touch(ctx));   // queued kernels may still read them
   for (void* p : ctx->scene_allocs) (void)hipFree(p);
   ctx->scene_allocs.clear();
   ctx->ds = DevScene{};
@@ -454,7 +469,7 @@ int verify_cull_flags(urt_context* ctx, const std::vector<int32_t>& words, const
   }
   URT_HIP(ctx, hipMemcpy(ctx->d_mesh_leaf, mesh_leaf.data(), mesh_leaf.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   int* mask = ctx->walk_f4 > 0 ? (int*)const_cast<float4*>(S.mesh_tlas + 2 * (size_t)S.n_mesh_tlas) + 6 : nullptr;      // header word [6] of the walk table behind the heap
-  URT_HIP(ctx, update_cull_flags(const_cast<float4*>(S.mesh_tlas), S.n_mesh_tlas, ctx->d_mesh_leaf, S.n_meshes, S.tri_verts, ctx->n_scene_tris, mask, ctx->stream));
+  URT_HIP(ctx, update_cull_flags(const_cast<float4*>(S.mesh_tlas), S.n_mesh_tlas, ctx->d_mesh_leaf, S.n_meshes, S.tri_verts, ctx->n_scene_tris, mask, touch(ctx)));
   return URT_OK;
 }
 
@@ -465,7 +480,7 @@ int rederive_nodes(urt_context* ctx) {
   DevScene& S = ctx->ds;
   S.blas_cnodes = nullptr;
   if (ctx->cbuf && ctx->n_blas_nodes > 0) {
-    URT_HIP(ctx, center_nodes(S.blas_nodes, ctx->n_blas_nodes, ctx->cbuf, ctx->stream));
+    URT_HIP(ctx, center_nodes(S.blas_nodes, ctx->n_blas_nodes, ctx->cbuf, touch(ctx)));
     S.blas_cnodes = ctx->cbuf;
   }
   return requantize(ctx);
@@ -475,10 +490,10 @@ int requantize(urt_context* ctx) {
   DevScene& S = ctx->ds;
   S.blas_qnodes = nullptr;
   if (ctx->opt_qnodes == 0 || !ctx->qbuf || ctx->n_blas_nodes <= 0) return URT_OK;
-  URT_HIP(ctx, quantize_nodes(S.blas_nodes, ctx->n_blas_nodes, S.mesh_root, S.n_meshes, ctx->qbuf, ctx->stream));
+  URT_HIP(ctx, quantize_nodes(S.blas_nodes, ctx->n_blas_nodes, S.mesh_root, S.n_meshes, ctx->qbuf, touch(ctx)));
   float4 f0;
-  URT_HIP(ctx, hipMemcpyAsync(&f0, ctx->qbuf, sizeof f0, hipMemcpyDeviceToHost, ctx->stream));
-  URT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  URT_HIP(ctx, hipMemcpyAsync(&f0, ctx->qbuf, sizeof f0, hipMemcpyDeviceToHost, touch(ctx)));
+  URT_HIP(ctx, hipStreamSynchronize(touch(ctx)));
   ctx->qnode_quality = f0.w;
   // one grid for the whole forest: a MeshObject that spans only a few hundred cells would have boxes of a few cells — every ray through
   // it would walk most of its tree.  Such scenes keep the float nodes (auto); "qnodes" = 1 insists.
@@ -534,7 +549,7 @@ int prepare_incremental(urt_context* ctx) {
     if (std::memcmp(a.localToWorldMatrix, b.localToWorldMatrix, 64) != 0 && b.indices_count >= 3) { moved[(size_t)m] = 1; n_moved++; }
   }
   if (n_moved > 0 && (!ctx->refit.ready || ctx->n_scene_tris <= 0)) return 1;
-  URT_HIP(ctx, hipStreamSynchronize(ctx->stream));           // frames in flight read the arrays that are about to change
+  URT_HIP(ctx, hipStreamSynchronize(touch(ctx)));           // frames in flight read the arrays that are about to change
   int rc;
   // materials: spheres, mesh objects, ground plane (pack_material: what Shade derives from the material alone)
   {
@@ -581,7 +596,7 @@ int prepare_incremental(urt_context* ctx) {
     URT_HIP(ctx, hipMemcpy(ctx->refit.moved, moved.data(), moved.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     URT_HIP(ctx, refit_moved(const_cast<float4*>(S.blas_nodes), ctx->n_blas_nodes, const_cast<float4*>(S.tri_verts), ctx->n_scene_tris,
                              ctx->refit.vertices, ctx->refit.indices, ctx->refit.depth, std::max(0, ctx->scene_max_depth - 1), ctx->refit.node_mesh,
-                             ctx->refit.matrices, ctx->refit.moved, ctx->refit.ext, n_meshes, ctx->refit.cbox, ctx->stream));
+                             ctx->refit.matrices, ctx->refit.moved, ctx->refit.ext, n_meshes, ctx->refit.cbox, touch(ctx)));
     ctx->refitted_meshes += (uint64_t)n_moved;
     if ((rc = rederive_nodes(ctx))) return rc;
   }
@@ -670,7 +685,7 @@ int prepare_scene(urt_context* ctx) {
       in.h_offsets = offs.data(); in.h_counts = cnts.data(); in.leaf_max = get_blas_leaf_max(); in.depth_budget = builder == 2; in.depth_slack = ctx->opt_lbvh_slack; in.sah = builder == 3;
       LbvhOutput o;
       std::string err;
-      rc = lbvh_build(in, ctx->stream, o, err);
+      rc = lbvh_build(in, touch(ctx), o, err);
       if (rc) { (void)hipFree(raw); return fail(ctx, rc, err); }
       ctx->scene_allocs.push_back(raw);                     // _Vertices / _Indices stay resident: a moved MeshObject is refitted from them
       ctx->refit.vertices = in.vertices; ctx->refit.indices = in.indices;
@@ -800,7 +815,7 @@ int prepare_scene(urt_context* ctx) {
     if ((rc = dev_alloc((void**)&R.ext, (size_t)n_meshes * 4))) return rc;
     if ((rc = dev_alloc((void**)&R.matrices, (size_t)n_meshes * 64))) return rc;
     if ((rc = dev_alloc((void**)&R.moved, (size_t)n_meshes * 4))) return rc;
-    URT_HIP(ctx, refit_prepare(S.blas_nodes, (int)n_blas_nodes, S.tri_verts, R.parent, R.node_mesh, R.depth, ctx->stream));
+    URT_HIP(ctx, refit_prepare(S.blas_nodes, (int)n_blas_nodes, S.tri_verts, R.parent, R.node_mesh, R.depth, touch(ctx)));
     R.ready = true;
   }
   ctx->scene_dirty = false; ctx->dirty_slots = 0; ctx->dirty_full = false;
@@ -860,7 +875,7 @@ bool in_slab(urt_context* ctx, const Texture& t) {
 // Give a texture its own storage back (its current contents are copied out of the slab slot they live in).
 int detach_from_slab(urt_context* ctx, Texture& t) {
   if (!in_slab(ctx, t)) return URT_OK;
-  URT_HIP(ctx, hipMemcpyAsync(t.own, t.dev, (size_t)t.w * t.h * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
+  URT_HIP(ctx, hipMemcpyAsync(t.own, t.dev, (size_t)t.w * t.h * sizeof(float4), hipMemcpyDeviceToDevice, touch(ctx)));
   t.dev = t.own;
   return URT_OK;
 }
@@ -880,7 +895,7 @@ int ensure_slab(urt_context* ctx, urt_handle h, Texture& t, int frames) {
   }
   if (!ctx->slab || ctx->slab_stride * (size_t)ctx->slab_frames < stride * (size_t)frames) {
     if (ctx->slab) {
-      URT_HIP(ctx, hipStreamSynchronize(ctx->stream));   // queued kernels may still use the old slab
+      URT_HIP(ctx, hipStreamSynchronize(touch(ctx)));   // queued kernels may still use the old slab
       (void)hipFree(ctx->slab);
       ctx->slab = nullptr; ctx->slab_frames = 0; ctx->slab_stride = 0;
     }
@@ -903,7 +918,7 @@ int ensure_slab(urt_context* ctx, urt_handle h, Texture& t, int frames) {
   }
   ctx->slab_stride = stride;
   if (ctx->slab_frames < 2) return URT_OK;               // (re-cut for a larger image: no room for two slots -> unbatched)
-  URT_HIP(ctx, hipMemsetAsync(ctx->slab, 0, stride * (size_t)ctx->slab_frames * sizeof(float4), ctx->stream));   // a new RenderTexture is zero-filled
+  URT_HIP(ctx, hipMemsetAsync(ctx->slab, 0, stride * (size_t)ctx->slab_frames * sizeof(float4), touch(ctx)));   // a new RenderTexture is zero-filled
   ctx->slab_tex = h;
   return URT_OK;
 }
@@ -1016,7 +1031,8 @@ void record_launch(urt_context* ctx, int kernel_mode, int front_mode, const Fram
 static constexpr int kAutoFrames = 64;     // frames per launch when "frames_per_launch" is 0 (auto) on the library's own stream
 
 int launch_sched_frames(urt_context* ctx, const DevScene& S, const FrameParams& P, const FrameTable& T, float4* result,
-                        int front_mode, bool count) {
+                        int front_mode, bool count, hipStream_t st = nullptr, unsigned int* next = nullptr) {
+  if (!st) { st = touch(ctx); next = ctx->d_next; }       // the main stream; flush_pending may pass one of its trace streams and that stream's work counters
   // the launch's frame table -> device memory, in stream order (pinned staging slot: the copy does not wait for the stream)
   if (!ctx->h_tables) {
     URT_HIP(ctx, hipHostMalloc((void**)&ctx->h_tables, sizeof(FrameUniforms) * kMaxFramesPerLaunch * urt_context::kTableSlots, hipHostMallocDefault));
@@ -1028,8 +1044,8 @@ int launch_sched_frames(urt_context* ctx, const DevScene& S, const FrameParams& 
   FrameUniforms* h_slot = ctx->h_tables + (size_t)slot * kMaxFramesPerLaunch;
   FrameUniforms* d_table = ctx->d_tables + (size_t)slot * kMaxFramesPerLaunch;
   std::memcpy(h_slot, T.f, sizeof(FrameUniforms) * (size_t)P.n_frames);
-  URT_HIP(ctx, hipMemcpyAsync(d_table, h_slot, sizeof(FrameUniforms) * (size_t)P.n_frames, hipMemcpyHostToDevice, ctx->stream));
-  URT_HIP(ctx, hipEventRecord(ctx->table_ev[slot], ctx->stream));
+  URT_HIP(ctx, hipMemcpyAsync(d_table, h_slot, sizeof(FrameUniforms) * (size_t)P.n_frames, hipMemcpyHostToDevice, st));
+  URT_HIP(ctx, hipEventRecord(ctx->table_ev[slot], st));
   int waves_per_block = P.block_threads / 64;
   long want = ((long)P.tiles_x * P.n_strips * P.n_frames + waves_per_block - 1) / waves_per_block;
   // resident waves per CU: every slot the registers allow (k_sched: 96 VGPRs -> 5 waves/SIMD = 20 per CU).  While the
@@ -1043,7 +1059,7 @@ int launch_sched_frames(urt_context* ctx, const DevScene& S, const FrameParams& 
   if (P.serve) {                                             // mailbox of the posted rays: 32 B per thread of the grid
     size_t slots = (size_t)nb * (size_t)P.block_threads;
     if (slots > ctx->mail_slots) {
-      if (ctx->d_mail) { URT_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->d_mail); ctx->d_mail = nullptr; ctx->mail_slots = 0; }
+      if (ctx->d_mail) { URT_HIP(ctx, hipStreamSynchronize(touch(ctx))); (void)hipFree(ctx->d_mail); ctx->d_mail = nullptr; ctx->mail_slots = 0; }
       URT_HIP(ctx, hipMalloc((void**)&ctx->d_mail, slots * 2 * sizeof(float4)));
       ctx->mail_slots = slots;
     }
@@ -1052,12 +1068,12 @@ int launch_sched_frames(urt_context* ctx, const DevScene& S, const FrameParams& 
   if (ctx->opt_time_dispatch) {
     int rc = take_event(ctx, &e0); if (rc) return rc;
     rc = take_event(ctx, &e1); if (rc) return rc;
-    URT_HIP(ctx, hipEventRecord(e0, ctx->stream));
+    URT_HIP(ctx, hipEventRecord(e0, st));
   }
-  hipError_t le = P.serve ? launch_serve(S, P, d_table, result, ctx->d_counters, ctx->d_next, ctx->d_mail, nb, front_mode, count, ctx->stream)
-                          : launch_sched(S, P, d_table, result, ctx->d_counters, ctx->d_next, nb, front_mode, count, ctx->stream);
+  hipError_t le = P.serve ? launch_serve(S, P, d_table, result, ctx->d_counters, next, ctx->d_mail, nb, front_mode, count, st)
+                          : launch_sched(S, P, d_table, result, ctx->d_counters, next, nb, front_mode, count, st);
   if (ctx->opt_time_dispatch) {
-    (void)hipEventRecord(e1, ctx->stream);
+    (void)hipEventRecord(e1, st);
     ctx->timing.emplace_back(e0, e1);
   }
   ctx->launches++;
@@ -1082,8 +1098,55 @@ int flush_pending(urt_context* ctx) {
   P.frame_group = std::max(1, std::min(P.frame_group, n));
   if (ctx->opt_xcd_run <= 0) P.xcd_run = auto_run_length(P, n);
   P.frame_stride = (unsigned int)ctx->slab_stride;
-  int rc = launch_sched_frames(ctx, B.S, P, B.T, ctx->slab, B.front_mode, B.count);
-  if (rc) return rc;
+  // Small launches (a host that presents every frame) overlap: see urt_context "Overlapped launches".  Launch L goes to trace stream
+  // L mod 2 and takes slots [base, base + n) round-robin; it waits for
+  //   - pre_ev of launch L-1: everything the main stream held when L-1 was submitted — the blends / presents of L-2 and older (the last
+  //     readers of any slot L may reuse), scene uploads, texture writes — but NOT launch L-1 itself nor its blends, whose slots are others;
+  //   - or, when anything but the frame loop's own work went to the main stream since (main_touched: SetData, a scene preparation, a
+  //     blit outside a batch, a gather, ...) or the slots would collide, for the main stream as it is now — which has waited for L-1.
+  // The main stream waits for the launch before its deferred blits, so "the main stream is idle" still means "everything is done".
+  int base = 0;
+  bool reading = false;                                  // a pipelined readback in flight: the host paces itself on FINISHED frames, and two launches sharing
+  for (const auto& r : ctx->rslot) reading = reading || r.busy;   // the chip finish later than one after the other (measured: +6 % C3, +21 % C2 with two tickets in flight)
+  const bool eligible = (ctx->opt_overlap == 2 || (ctx->opt_overlap == 1 && !reading)) && ctx->stream == ctx->own_stream && !P.serve && !ctx->opt_time_dispatch &&
+                        n <= urt_context::kOverlapFrames && ctx->slab_frames >= 2 * urt_context::kOverlapFrames && ctx->d_next2;
+  if (eligible) {
+    base = ctx->slab_cursor + n <= ctx->slab_frames ? ctx->slab_cursor : 0;
+    if (!ctx->trace_q[0]) {
+      for (int k = 0; k < 2; k++) {
+        URT_HIP(ctx, hipStreamCreateWithFlags(&ctx->trace_q[k], hipStreamNonBlocking));
+        URT_HIP(ctx, hipEventCreateWithFlags(&ctx->trace_done[k], hipEventDisableTiming));
+        URT_HIP(ctx, hipEventCreateWithFlags(&ctx->pre_ev[k], hipEventDisableTiming));
+      }
+      URT_HIP(ctx, hipEventCreateWithFlags(&ctx->dep_ev, hipEventDisableTiming));
+    }
+    const unsigned int k = ctx->trace_parity++ & 1u;
+    const bool disjoint = base >= ctx->prev_base + ctx->prev_n || base + n <= ctx->prev_base;
+    if (ctx->main_touched || !disjoint) {
+      URT_HIP(ctx, hipEventRecord(ctx->dep_ev, ctx->stream));
+      URT_HIP(ctx, hipStreamWaitEvent(ctx->trace_q[k], ctx->dep_ev, 0));
+    } else {
+      URT_HIP(ctx, hipStreamWaitEvent(ctx->trace_q[k], ctx->pre_ev[k ^ 1u], 0));
+      ctx->overlapped_launches++;
+    }
+    const bool narrow = !(ctx->main_touched || !disjoint);
+    int rc = launch_sched_frames(ctx, B.S, P, B.T, ctx->slab + (size_t)base * ctx->slab_stride, B.front_mode, B.count, ctx->trace_q[k], k ? ctx->d_next2 : ctx->d_next);
+    if (rc) { ctx->main_touched = true; return rc; }
+    ctx->last_launch.trace_stream = 1 + (int)k; ctx->last_launch.slab_base = base; ctx->last_launch.overlapped = narrow ? 1 : 0;
+    URT_HIP(ctx, hipEventRecord(ctx->trace_done[k], ctx->trace_q[k]));
+    URT_HIP(ctx, hipEventRecord(ctx->pre_ev[k], ctx->stream));
+    URT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->trace_done[k], 0));
+    ctx->main_touched = false;
+  } else {
+    int rc = launch_sched_frames(ctx, B.S, P, B.T, ctx->slab, B.front_mode, B.count);     // on the main stream (marks it touched)
+    if (rc) return rc;
+  }
+  ctx->prev_base = base; ctx->prev_n = n; ctx->slab_cursor = base + n;
+  if (base) {                                            // the Result texture names the LAST frame's slot (do_dispatch named it assuming slot 0)
+    Texture* rt = find_texture(ctx, B.tex);
+    if (rt && in_slab(ctx, *rt)) rt->dev = ctx->slab + (size_t)(base + n - 1) * ctx->slab_stride;
+  }
+  const float4* const slots = ctx->slab + (size_t)base * ctx->slab_stride;
   size_t i = 0;
   while (i < ops.size()) {
     const urt_context::PostOp& op = ops[i];
@@ -1113,7 +1176,7 @@ int flush_pending(urt_context* ctx) {
         if (!pt) return fail(ctx, URT_ERR_INVALID_HANDLE, "deferred Blit: destination texture was released");
         pdev = pt->dev;
       }
-      const float4* src = ctx->slab + (size_t)op.frame * ctx->slab_stride;
+      const float4* src = slots + (size_t)op.frame * ctx->slab_stride;
       hipError_t e = (cnt == 1 && !pdev) ? launch_blit_add(src, d->dev, (size_t)d->w * d->h, samples[0], ctx->stream)
                                          : launch_blit_add_multi(src, ctx->slab_stride, cnt, samples, d->dev, pdev, (size_t)d->w * d->h, ctx->stream);
       if (e != hipSuccess) return fail(ctx, URT_ERR_HIP, std::string("deferred Blit: ") + hipGetErrorString(e));
@@ -1122,13 +1185,13 @@ int flush_pending(urt_context* ctx) {
       Texture* t = find_texture(ctx, op.tex);
       Texture* d = find_texture(ctx, op.dst);
       if (!t || !d) return fail(ctx, URT_ERR_INVALID_HANDLE, "deferred Blit: texture was released");
-      const float4* img = op.tex == B.tex ? ctx->slab + (size_t)op.frame * ctx->slab_stride : t->dev;
+      const float4* img = op.tex == B.tex ? slots + (size_t)op.frame * ctx->slab_stride : t->dev;
       URT_HIP(ctx, hipMemcpyAsync(d->dev, img, (size_t)t->w * t->h * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
       i++;
     } else {
       Texture* t = find_texture(ctx, op.tex);
       if (!t) return fail(ctx, URT_ERR_INVALID_HANDLE, "deferred pack_rows: texture was released");
-      const float4* img = op.tex == B.tex ? ctx->slab + (size_t)op.frame * ctx->slab_stride : t->dev;
+      const float4* img = op.tex == B.tex ? slots + (size_t)op.frame * ctx->slab_stride : t->dev;
       int group_rows = (t->h + 7) / 8;
       int n_strips = op.first_row < group_rows ? (group_rows - op.first_row + op.row_stride - 1) / op.row_stride : 0;
       hipError_t e = op.sample != 0.0f ? launch_pack_rows_rgb(const_cast<float4*>(img), (float*)op.dense, t->w, t->h, op.first_row, op.row_stride, n_strips, true, 0.0f, ctx->stream)
@@ -1178,7 +1241,7 @@ int do_dispatch(urt_context* ctx, int kernel, int gx, int gy, int gz, int first_
   else {     // an unbound SRV reads zeros
     if (!ctx->zero_sky) {
       URT_HIP(ctx, hipMalloc((void**)&ctx->zero_sky, sizeof(float4)));
-      URT_HIP(ctx, hipMemsetAsync(ctx->zero_sky, 0, sizeof(float4), ctx->stream));
+      URT_HIP(ctx, hipMemsetAsync(ctx->zero_sky, 0, sizeof(float4), touch(ctx)));
     }
     S.sky = ctx->zero_sky; S.sky_w = 1; S.sky_h = 1;
   }
@@ -1282,10 +1345,10 @@ int do_dispatch(urt_context* ctx, int kernel, int gx, int gy, int gz, int first_
     if (ctx->opt_time_dispatch) {
       rc = take_event(ctx, &e0); if (rc) return rc;
       rc = take_event(ctx, &e1); if (rc) return rc;
-      URT_HIP(ctx, hipEventRecord(e0, ctx->stream));
+      URT_HIP(ctx, hipEventRecord(e0, touch(ctx)));
     }
     hipError_t le;
-    if (mode == 1) le = launch_wavefront(S, P, ctx->q, res->dev, ctx->d_counters, count, ctx->stream);
+    if (mode == 1) le = launch_wavefront(S, P, ctx->q, res->dev, ctx->d_counters, count, touch(ctx));
     else if (mode == 2) {
       int waves_per_block = P.block_threads / 64;
       long want = ((long)P.tiles_x * P.n_strips + waves_per_block - 1) / waves_per_block;
@@ -1293,7 +1356,7 @@ int do_dispatch(urt_context* ctx, int kernel, int gx, int gy, int gz, int first_
       if (wpc <= 0) wpc = 20;
       long resident = (long)ctx->n_cus * wpc / waves_per_block;
       int nb = (int)std::max(1L, std::min(want, resident));
-      le = launch_persist(S, P, res->dev, ctx->d_counters, ctx->d_next, nb, count, ctx->stream);
+      le = launch_persist(S, P, res->dev, ctx->d_counters, ctx->d_next, nb, count, touch(ctx));
     } else if (mode == 4) {
       // one wave per workgroup; residency is bounded by the LDS one wave's path pool takes (kernels.hip k_pool)
       P.block_threads = 64;
@@ -1307,10 +1370,10 @@ int do_dispatch(urt_context* ctx, int kernel, int gx, int gy, int gz, int first_
       int wpc = ctx->opt_waves_per_cu > 0 ? ctx->opt_waves_per_cu : fit;
       long want = ((long)P.tiles_x * P.n_strips * 64 + 64L * k - 1) / (64L * k);
       int nb = (int)std::max(1L, std::min(want, (long)ctx->n_cus * wpc));
-      le = launch_pool(S, P, res->dev, ctx->d_counters, ctx->d_next, nb, k, count, ctx->stream);
-    } else le = launch_mega(S, P, res->dev, ctx->d_counters, count, ctx->stream);
+      le = launch_pool(S, P, res->dev, ctx->d_counters, ctx->d_next, nb, k, count, touch(ctx));
+    } else le = launch_mega(S, P, res->dev, ctx->d_counters, count, touch(ctx));
     if (ctx->opt_time_dispatch) {
-      (void)hipEventRecord(e1, ctx->stream);
+      (void)hipEventRecord(e1, touch(ctx));
       ctx->timing.emplace_back(e0, e1);
     }
     ctx->launches++;
@@ -1357,12 +1420,15 @@ int urt_context_create(int device, urt_context** out_ctx) {
   if (e == hipSuccess) e = hipMemset(ctx->d_counters, 0, sizeof(DevCounters) * kCounterShards);
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_next, kWorkShards * 128 + 65536 * 16 * sizeof(unsigned long long));   // work-counter shards; the rest: diagnostic stamps (URT_STAMPS builds)
   if (e == hipSuccess) e = hipMemset(ctx->d_next, 0, kWorkShards * 128 + 65536 * 16 * sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_next2, kWorkShards * 128 + 65536 * 16 * sizeof(unsigned long long));    // the launch on the second trace stream (same layout)
+  if (e == hipSuccess) e = hipMemset(ctx->d_next2, 0, kWorkShards * 128 + 65536 * 16 * sizeof(unsigned long long));
   if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->h_trip_flag, 64, hipHostMallocMapped | hipHostMallocCoherent);   // the watchdog word the kernels raise (system-scope atomic)
   if (e == hipSuccess) { *ctx->h_trip_flag = 0; e = hipHostGetDevicePointer((void**)&ctx->d_trip_flag, ctx->h_trip_flag, 0); }
   if (e == hipSuccess) { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n > 0) ctx->n_cus = n; }
   if (e != hipSuccess) {
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->d_next) (void)hipFree(ctx->d_next);
+    if (ctx->d_next2) (void)hipFree(ctx->d_next2);
     if (ctx->h_trip_flag) (void)hipHostFree(ctx->h_trip_flag);
     (void)hipStreamDestroy(ctx->own_stream); delete ctx;
     return fail(nullptr, URT_ERR_HIP, std::string("counter allocation: ") + hipGetErrorString(e));
@@ -1376,7 +1442,7 @@ int urt_context_destroy(urt_context* ctx) {
   if (!ctx) return URT_OK;
   (void)hipSetDevice(ctx->device);
   (void)flush_pending(ctx);
-  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipStreamSynchronize(touch(ctx));
   resolve_timing(ctx);
   free_scene(ctx);
   for (auto& kv : ctx->textures) if (!kv.second.external && kv.second.own) (void)hipFree(kv.second.own);
@@ -1388,6 +1454,7 @@ int urt_context_destroy(urt_context* ctx) {
   if (ctx->zero_sky) (void)hipFree(ctx->zero_sky);
   if (ctx->d_counters) (void)hipFree(ctx->d_counters);
   if (ctx->d_next) (void)hipFree(ctx->d_next);
+  if (ctx->d_next2) (void)hipFree(ctx->d_next2);
   if (ctx->d_mail) (void)hipFree(ctx->d_mail);
   if (ctx->d_tables) (void)hipFree(ctx->d_tables);
   if (ctx->h_tables) (void)hipHostFree(ctx->h_tables);
@@ -1401,6 +1468,12 @@ int urt_context_destroy(urt_context* ctx) {
   }
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   if (ctx->srgb_first) (void)hipFree(ctx->srgb_first);
+  for (int k = 0; k < 2; k++) {
+    if (ctx->trace_q[k]) { (void)hipStreamSynchronize(ctx->trace_q[k]); (void)hipStreamDestroy(ctx->trace_q[k]); }
+    if (ctx->trace_done[k]) (void)hipEventDestroy(ctx->trace_done[k]);
+    if (ctx->pre_ev[k]) (void)hipEventDestroy(ctx->pre_ev[k]);
+  }
+  if (ctx->dep_ev) (void)hipEventDestroy(ctx->dep_ev);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
   return URT_OK;
@@ -1417,7 +1490,7 @@ int urt_context_set_stream(urt_context* ctx, void* hip_stream) {
   // no host synchronisation: everything issued so far on the old stream is ordered before whatever is issued on the new
   // one by an event (a caller that ping-pongs between a render and a communication stream must not stall on either)
   if (!ctx->ev_switch) URT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_switch, hipEventDisableTiming));
-  URT_HIP(ctx, hipEventRecord(ctx->ev_switch, ctx->stream));
+  URT_HIP(ctx, hipEventRecord(ctx->ev_switch, touch(ctx)));
   URT_HIP(ctx, hipStreamWaitEvent(to, ctx->ev_switch, 0));
   ctx->stream = to;
   return URT_OK;
@@ -1434,7 +1507,7 @@ int urt_synchronize(urt_context* ctx) {
   if (!ctx) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "ctx is NULL");
   URT_HIP(ctx, hipSetDevice(ctx->device));
   { int rc = flush_pending(ctx); if (rc) return rc; }
-  URT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  URT_HIP(ctx, hipStreamSynchronize(touch(ctx)));
   return check_watchdog(ctx);
 }
 
@@ -1501,7 +1574,7 @@ static int texture_create_impl(urt_context* ctx, int width, int height, void* ex
   if (ext) { t.dev = (float4*)ext; t.external = true; t.other_writes = true; /* caller memory: contents unknown */ }
   else {
     URT_HIP(ctx, hipMalloc((void**)&t.dev, bytes));
-    hipError_t e = hipMemsetAsync(t.dev, 0, bytes, ctx->stream);
+    hipError_t e = hipMemsetAsync(t.dev, 0, bytes, touch(ctx));
     if (e != hipSuccess) { (void)hipFree(t.dev); return fail(ctx, URT_ERR_HIP, std::string("hipMemsetAsync: ") + hipGetErrorString(e)); }
   }
   t.own = t.dev;
@@ -1529,8 +1602,8 @@ int urt_texture_set_pixels(urt_context* ctx, urt_handle texture, const float* rg
   URT_HIP(ctx, hipSetDevice(ctx->device));
   { int rc = flush_pending(ctx); if (rc) return rc; }
   t->other_writes = true;
-  URT_HIP(ctx, hipMemcpyAsync(t->dev, rgba, (size_t)t->w * t->h * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
-  URT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  URT_HIP(ctx, hipMemcpyAsync(t->dev, rgba, (size_t)t->w * t->h * sizeof(float4), hipMemcpyHostToDevice, touch(ctx)));
+  URT_HIP(ctx, hipStreamSynchronize(touch(ctx)));
   return URT_OK;
 }
 
@@ -1541,8 +1614,8 @@ int urt_texture_get_pixels(urt_context* ctx, urt_handle texture, float* rgba) {
   if (!rgba) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "rgba is NULL");
   URT_HIP(ctx, hipSetDevice(ctx->device));
   { int rc = flush_pending(ctx); if (rc) return rc; }
-  URT_HIP(ctx, hipMemcpyAsync(rgba, t->dev, (size_t)t->w * t->h * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
-  URT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  URT_HIP(ctx, hipMemcpyAsync(rgba, t->dev, (size_t)t->w * t->h * sizeof(float4), hipMemcpyDeviceToHost, touch(ctx)));
+  URT_HIP(ctx, hipStreamSynchronize(touch(ctx)));
   return check_watchdog(ctx);                           // pixels of a launch that hit a cap are not handed out as good
 }
 
@@ -1649,7 +1722,7 @@ int urt_texture_release(urt_context* ctx, urt_handle texture) {
   if (it == ctx->textures.end()) return fail(ctx, URT_ERR_INVALID_HANDLE, "Release: unknown texture handle");
   URT_HIP(ctx, hipSetDevice(ctx->device));
   { int rc = flush_pending(ctx); if (rc) return rc; }
-  URT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  URT_HIP(ctx, hipStreamSynchronize(touch(ctx)));
   if (!it->second.external && it->second.own) (void)hipFree(it->second.own);
   ctx->slab_oom_stride = 0;                                // device memory came back: the next batch may try the Result slots again
   if (ctx->slab_tex == texture) ctx->slab_tex = 0;
@@ -1751,7 +1824,7 @@ int urt_blit_add(urt_context* ctx, urt_handle src, urt_handle dst, float sample)
     return URT_OK;
   }
   { int rc = flush_pending(ctx); if (rc) return rc; }
-  URT_HIP(ctx, launch_blit_add(s->dev, d->dev, (size_t)s->w * s->h, sample, ctx->stream));
+  URT_HIP(ctx, launch_blit_add(s->dev, d->dev, (size_t)s->w * s->h, sample, touch(ctx)));
   return URT_OK;
   URT_GUARD_END(ctx)
 }
@@ -1776,7 +1849,7 @@ int urt_blit(urt_context* ctx, urt_handle src, urt_handle dst) {
   { int rc = flush_pending(ctx); if (rc) return rc; }
   d->other_writes = true;
   if (dst != src)
-    URT_HIP(ctx, hipMemcpyAsync(d->dev, s->dev, (size_t)s->w * s->h * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
+    URT_HIP(ctx, hipMemcpyAsync(d->dev, s->dev, (size_t)s->w * s->h * sizeof(float4), hipMemcpyDeviceToDevice, touch(ctx)));
   return URT_OK;
   URT_GUARD_END(ctx)
 }
@@ -1801,8 +1874,8 @@ static int pack_impl(urt_context* ctx, urt_handle texture, int first_group_row, 
   { int rc = flush_pending(ctx); if (rc) return rc; }
   if (!to_dense) t->other_writes = true;
   URT_GUARD_END(ctx)
-  if (rgb) URT_HIP(ctx, launch_pack_rows_rgb(t->dev, (float*)dense, t->w, t->h, first_group_row, row_stride, n_strips, to_dense, alpha, ctx->stream));
-  else URT_HIP(ctx, launch_pack_rows(t->dev, (float4*)dense, t->w, t->h, first_group_row, row_stride, n_strips, to_dense, ctx->stream));
+  if (rgb) URT_HIP(ctx, launch_pack_rows_rgb(t->dev, (float*)dense, t->w, t->h, first_group_row, row_stride, n_strips, to_dense, alpha, touch(ctx)));
+  else URT_HIP(ctx, launch_pack_rows(t->dev, (float4*)dense, t->w, t->h, first_group_row, row_stride, n_strips, to_dense, touch(ctx)));
   return URT_OK;
 }
 
@@ -1957,6 +2030,10 @@ int urt_set_option(urt_context* ctx, const char* name, int value) {
     if (value < 0 || value > 16) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "lbvh_slack must be 0..16");
     if (value != ctx->opt_lbvh_slack) { ctx->scene_dirty = true; ctx->dirty_full = true; }
     ctx->opt_lbvh_slack = value;
+  } else if (std::strcmp(name, "overlap_launches") == 0) {
+    if (value < 0 || value > 2) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "overlap_launches must be 0 (off), 1 (auto) or 2 (always)");
+    { int rc = flush_pending(ctx); if (rc) return rc; }
+    ctx->opt_overlap = value;
   } else if (std::strcmp(name, "front_cull") == 0) {
     if (value < 0 || value > 1) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "front_cull must be 0 or 1");
     if (ctx->opt_front_cull != value) { int rc = flush_pending(ctx); if (rc) return rc; ctx->opt_front_cull = value; ctx->scene_dirty = true; ctx->dirty_full = true; }
@@ -1978,7 +2055,7 @@ int urt_get_counters(urt_context* ctx, urt_counters* out) {
   if (!out) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "out is NULL");
   URT_HIP(ctx, hipSetDevice(ctx->device));
   { int rc = flush_pending(ctx); if (rc) return rc; }
-  URT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  URT_HIP(ctx, hipStreamSynchronize(touch(ctx)));
   resolve_timing(ctx);
   std::vector<DevCounters> shards(kCounterShards);
   URT_HIP(ctx, hipMemcpy(shards.data(), ctx->d_counters, sizeof(DevCounters) * kCounterShards, hipMemcpyDeviceToHost));
@@ -2000,7 +2077,7 @@ int urt_reset_counters(urt_context* ctx) {
   if (!ctx) return fail(nullptr, URT_ERR_INVALID_ARGUMENT, "ctx is NULL");
   URT_HIP(ctx, hipSetDevice(ctx->device));
   { int rc = flush_pending(ctx); if (rc) return rc; }
-  URT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  URT_HIP(ctx, hipStreamSynchronize(touch(ctx)));
   resolve_timing(ctx);
   URT_HIP(ctx, hipMemset(ctx->d_counters, 0, sizeof(DevCounters) * kCounterShards));
   if (ctx->h_trip_flag) __atomic_store_n(ctx->h_trip_flag, 0u, __ATOMIC_RELEASE);
@@ -2014,7 +2091,7 @@ int urt_reset_counters(urt_context* ctx) {
 #ifdef URT_STAMPS
 /* diagnostic builds only: per-wave (start, pool-exhausted, end, iters<<32|fetches) of the last persistent launch */
 __attribute__((visibility("default"))) int urt_debug_read_stamps(urt_context* ctx, unsigned long long* out, int n_waves) {
-  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipStreamSynchronize(touch(ctx));
   hipError_t e = hipMemcpy(out, (char*)ctx->d_next + kWorkShards * 128, (size_t)n_waves * sizeof(unsigned long long), hipMemcpyDeviceToHost);   // n_waves = number of u64 words
   (void)hipMemset((char*)ctx->d_next + kWorkShards * 128, 0, 65536 * 16 * sizeof(unsigned long long));
   return (int)e;
@@ -2028,7 +2105,7 @@ int urt_debug_serve_stats(urt_context* ctx, unsigned long long* out6) {
   if (!out6) return fail(ctx, URT_ERR_INVALID_ARGUMENT, "out6 is NULL");
   URT_HIP(ctx, hipSetDevice(ctx->device));
   { int rc = flush_pending(ctx); if (rc) return rc; }
-  URT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  URT_HIP(ctx, hipStreamSynchronize(touch(ctx)));
   std::vector<DevCounters> shards(kCounterShards);
   URT_HIP(ctx, hipMemcpy(shards.data(), ctx->d_counters, sizeof(DevCounters) * kCounterShards, hipMemcpyDeviceToHost));
   for (int q = 0; q < 6; q++) out6[q] = 0;
@@ -2093,6 +2170,7 @@ int urt_debug_launch_info(urt_context* ctx, urt_launch_info* out) {
   *out = ctx->last_launch;
   out->slab_frames = ctx->slab_frames; out->slab_frames_max = ctx->slab_frames_max; out->slab_out_of_memory = ctx->slab_oom_stride != 0 ? 1 : 0;
   out->blas_builder = ctx->last_builder;
+  out->overlapped_launches = (int)std::min<uint64_t>(ctx->overlapped_launches, 0x7fffffff);
   return URT_OK;
 }
 
@@ -2114,7 +2192,7 @@ int urt_debug_read_scene_blas(urt_context* ctx, float* nodes, int32_t* tri_index
   URT_GUARD_BEGIN
   URT_HIP(ctx, hipSetDevice(ctx->device));
   if (ctx->scene_dirty) { int rc = flush_pending(ctx); if (rc) return rc; rc = prepare_scene(ctx); if (rc) return rc; }
-  URT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  URT_HIP(ctx, hipStreamSynchronize(touch(ctx)));
   const DevScene& S = ctx->ds;
   if (nodes && ctx->n_blas_nodes > 0) URT_HIP(ctx, hipMemcpy(nodes, S.blas_nodes, (size_t)ctx->n_blas_nodes * kBlasNodeFloats * sizeof(float), hipMemcpyDeviceToHost));
   if (mesh_root && S.n_meshes > 0) URT_HIP(ctx, hipMemcpy(mesh_root, S.mesh_root, (size_t)S.n_meshes * sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -2140,7 +2218,7 @@ int urt_debug_get_blas(float* nodes, int32_t* tri_index, int32_t* mesh_root, int
 
 // ---- internal accessors for group.cpp (not part of the C ABI) ----------------------------------------------------------
 namespace urtd {
-hipStream_t context_stream(urt_context* ctx) { return ctx->stream; }
+hipStream_t context_stream(urt_context* ctx) { return touch(ctx); }   // (csrc/group.cpp enqueues gathers and blits on it)
 int context_device(urt_context* ctx) { return ctx->device; }
 int context_pending_frames(urt_context* ctx) { return ctx->pend.n; }
 }  // namespace urtd
