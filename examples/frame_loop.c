@@ -134,6 +134,17 @@ int main(int argc, char** argv) {
   urt_counters c;
   CHECK(ctx, urt_get_counters(ctx, &c));
   char path[1024];
+  /* the same present as an 8-bit sRGB back buffer would hold it (RM:819 into the camera's target), converted on the GPU and read back
+   * without stalling the stream: begin ... (a real host would submit the next frames here) ... end */
+  uint64_t ticket = 0;
+  const void* rgba8 = NULL;
+  size_t rgba8_bytes = 0;
+  CHECK(ctx, urt_texture_read_begin_format(ctx, destination, URT_FORMAT_RGBA8_SRGB, &ticket));
+  CHECK(ctx, urt_texture_read_end_format(ctx, ticket, &rgba8, &rgba8_bytes));
+  snprintf(path, sizeof path, "%s.rgba8", out);
+  FILE* f8 = fopen(path, "wb");
+  if (!f8 || rgba8_bytes != (size_t)W * H * 4 || fwrite(rgba8, rgba8_bytes, 1, f8) != 1) { fprintf(stderr, "cannot write %s\n", path); return 3; }
+  fclose(f8);
   snprintf(path, sizeof path, "%s.pfm", out);
   CHECK(ctx, urt_host_write_pfm(path, image, W, H));
   snprintf(path, sizeof path, "%s.png", out);

@@ -81,4 +81,6 @@ def test_c99_host_matches_python_host(gpu_ctx, tmp_path):
     ref_png = str(tmp_path / "py.png")
     host_io.write_png(ref_png, want)
     assert open(out + ".png", "rb").read() == open(ref_png, "rb").read()
+    got8 = np.fromfile(out + ".rgba8", dtype=np.uint8).reshape(96, 160, 4)     # urt_texture_read_begin_format(URT_FORMAT_RGBA8_SRGB) from C
+    assert np.array_equal(got8, host_io.encode_srgb8(want))
     assert (got[..., :3] > 0).mean() > 0.9                      # a real picture, not zeros

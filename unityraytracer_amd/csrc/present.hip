@@ -38,6 +38,7 @@ __device__ __forceinline__ unsigned int unorm8(float a) {
 }
 
 __global__ __launch_bounds__(256) void k_encode_srgb8(const float4* __restrict__ src, uint32_t* __restrict__ dst, size_t pixels, const float* __restrict__ first_g) {
+  static_assert(kSrgbCodes == 256, "one table entry per thread of the 256-thread block");
   __shared__ float first[kSrgbCodes];
   first[threadIdx.x] = first_g[threadIdx.x];
   __syncthreads();
