@@ -948,6 +948,15 @@ static int configure_sched_at(urt_context* ctx, const DevScene& S, FrameParams& 
   P.top_nodes = t;
   const size_t budget = 156 * 1024;                          // (a little of the 160 KiB goes to allocation granules)
   while (P.top_nodes > 0 && sched_lds_bytes(S, P) * groups > budget) P.top_nodes /= 2;
+  if (ctx->opt_top_nodes < 0 && P.top_nodes == 64) {
+    // auto: what is left of the workgroup's share of the LDS holds more of the forest's top, 16 nodes (1 KiB) at a time — C3 / C3D: 96 nodes,
+    // -0.6 % per frame in 64-frame launches (profiles/r04_logs/r4_sweep_top_nodes.log); every node there is a fetch at LDS latency
+    const int most = std::min((int)kTopOrderNodes, ctx->n_blas_nodes);
+    while (P.top_nodes + 16 <= most) {
+      P.top_nodes += 16;
+      if (sched_lds_bytes(S, P) * groups > budget) { P.top_nodes -= 16; break; }
+    }
+  }
   if (sched_lds_bytes(S, P) * groups > budget) { P.lds_mesh = 0; P.lds_sphere = 0; P.lds_small = 0; }
   *degraded = (t > 0 && P.top_nodes == 0) || (wanted_tables && !(P.lds_mesh || P.lds_sphere)) || sched_lds_bytes(S, P) * groups > budget;
   // listed FRONT (kernels.hip front_listed): scenes of a few MeshObjects whose heap is in LDS; the list of objects a ray has to test
